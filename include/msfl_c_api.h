@@ -1,0 +1,322 @@
+/*
+ * msfl_c_api.h — C ABI of the MI355X-native LOAM scan-matching engine (libmsfl_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of kekeliu-whu/MSF_LOAM:
+ *   stage A  per-scan feature extraction      reference src/msf_loam_node.cc:160-378
+ *   stage B  scan-to-scan registration        reference src/slam/local/scan_matching/odometry_scan_matcher.cc:43-285
+ *   stage C  scan-to-local-map registration   reference src/slam/local/scan_matching/mapping_scan_matcher.cc:19-278
+ *
+ * Plain C, plain pointers and sizes, no torch / PCL / Eigen / Ceres types. Every entry point
+ * cites the reference interface it replaces.  A maintainer-side binding (C++ adapter with the
+ * reference's own method signatures) is shown in INTEGRATION.md and shipped as
+ * include/msfl_scan_matcher.hpp.
+ *
+ * Conventions
+ *   - Points are 16-byte records {x, y, z, t}.  `t` is what the reference keeps in
+ *     pcl::PointXYZI::intensity, i.e. the per-point relative time in seconds
+ *     (msf_loam_node.cc:152-153 writes time into intensity).
+ *   - A pose is 7 doubles [tx ty tz qx qy qz qw], the layout of Rigid3d::ToVector7()
+ *     (src/common/rigid_transform.h:59-64).  Poses are IN/OUT: initial guess in, result out,
+ *     exactly like the reference's `Rigid3d *pose_estimate` arguments.
+ *   - Every pointer argument is tagged by a `mem` flag: MSFL_MEM_HOST (the library stages the
+ *     copy) or MSFL_MEM_DEVICE (already resident in HBM on the handle's device; nothing is copied).
+ *   - All functions return an msfl_status.  No exceptions, no aborts: the reference's glog CHECK
+ *     failures and out-of-bounds reads (SURVEY.md §8b "edge cases") become status codes.
+ *   - A handle owns one HIP stream and all device scratch.  Handles are independent, so the
+ *     odometry thread and the mapping thread of the reference (laser_odometry.h:29,
+ *     laser_mapping.h:65) each own one and may call concurrently.  A single handle is not
+ *     re-entrant (neither is a reference matcher instance).
+ */
+#ifndef MSFL_C_API_H_
+#define MSFL_C_API_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSFL_API_VERSION 1
+
+typedef struct msfl_handle_s msfl_handle;
+
+typedef enum msfl_status {
+  MSFL_OK = 0,
+  /* odometry_scan_matcher.cc:262-267 returns false when corner+plane correspondences < 10.
+     Per-scan status in batched calls; the pose keeps the value of the last completed solve. */
+  MSFL_TOO_FEW_CORRESPONDENCES = 1,
+  /* mapping_scan_matcher.cc:128,198 index pointSearchSqDis[4] unguarded; the reference relies on
+     the caller's gate (laser_mapping.cc:284-285).  Here: map cloud with < 5 points. */
+  MSFL_MAP_TOO_SMALL = 2,
+  MSFL_BAD_ARG = 3,
+  MSFL_HIP_ERROR = 4,
+  /* msf_loam_node.cc:136 CHECK_LT(point.ring, 128) / :186 CHECK_GT(valid_scan_num, 0) */
+  MSFL_BAD_RING = 5,
+  MSFL_NO_MAP = 6,
+  MSFL_CAPACITY = 7
+} msfl_status;
+
+typedef enum msfl_mem { MSFL_MEM_HOST = 0, MSFL_MEM_DEVICE = 1 } msfl_mem;
+
+/* 16-byte point: pcl::PointXYZI as the matchers see it (x,y,z + intensity==relative time). */
+typedef struct msfl_point {
+  float x, y, z, t;
+} msfl_point;
+
+/*
+ * All hot-path thresholds of the reference are compile-time constants (SURVEY.md §8a
+ * "Constants").  They are exposed as a POD with the reference values as defaults
+ * (msfl_default_params).  Parity claims hold for the defaults.
+ */
+typedef struct msfl_params {
+  /* --- stage A, msf_loam_node.cc --- */
+  double scan_period;            /* kScanPeriod = 0.1                     :80      */
+  double min_range;              /* g_min_range, launch default 0.3       :434     */
+  float  curvature_threshold;    /* 0.1                                   :275,312 */
+  float  neighbor_gap_sq;        /* 0.05                                  :293,300 */
+  int    sectors_per_ring;       /* 6                                     :255     */
+  int    max_sharp_per_sector;   /* 2                                     :277     */
+  int    max_less_sharp_per_sector; /* 20                                 :281     */
+  int    max_flat_per_sector;    /* 4                                     :317     */
+  /* --- stage B, odometry_scan_matcher.cc:15-18 --- */
+  double odom_distance_sq_threshold; /* kDistanceSqThreshold = 25 */
+  double odom_nearby_scan;           /* kNearByScan = 2.5         */
+  int    odom_min_correspondences;   /* 10, :262                  */
+  /* --- stage C, mapping_scan_matcher.cc --- */
+  int    map_knn;                /* 5 (fixed by the kernels; other values -> MSFL_BAD_ARG) :125 */
+  float  map_knn_max_sq_dist;    /* 1.0   :128,198 */
+  double line_eigen_ratio;       /* 3.0   :147     */
+  double plane_tolerance;        /* 0.2   :216     */
+  /* --- shared solver settings (both matchers) --- */
+  int    outer_iterations;       /* kOptimalNum = 2, mapping_scan_matcher.cc:15 */
+  int    max_lm_iterations;      /* options.max_num_iterations = 6, :252 */
+  double huber_delta;            /* ceres::HuberLoss(0.1), :77 */
+  /* Ceres Solver::Options defaults the reference leaves untouched (third party, not in tree). */
+  double initial_trust_region_radius; /* 1e4   */
+  double max_trust_region_radius;     /* 1e16  */
+  double min_trust_region_radius;     /* 1e-32 */
+  double min_relative_decrease;       /* 1e-3  */
+  double min_lm_diagonal;             /* 1e-6  */
+  double max_lm_diagonal;             /* 1e32  */
+  double function_tolerance;          /* 1e-6  */
+  double gradient_tolerance;          /* 1e-10 */
+  double parameter_tolerance;         /* 1e-8  */
+  int    max_consecutive_invalid_steps; /* 5 */
+} msfl_params;
+
+/* Per-registration diagnostics (what the reference only logs via glog / Ceres BriefReport). */
+typedef struct msfl_match_info {
+  int    status;             /* msfl_status of this scan */
+  int    n_edge[2];          /* accepted edge correspondences, outer iteration 0 / 1  (corner_num :173) */
+  int    n_plane[2];         /* accepted plane correspondences (surf_num :243) */
+  int    lm_iterations[2];   /* trust-region iterations executed (<= max_lm_iterations) */
+  int    lm_successful[2];   /* accepted steps */
+  double initial_cost[2];    /* Ceres cost (1/2 sum rho) at entry of each solve */
+  double final_cost[2];      /* cost at the returned pose */
+} msfl_match_info;
+
+/* Accumulated GPU time per kernel class, measured with HIP events on the handle's stream
+   (enabled by msfl_set_timing).  Used by bench.py for the live roofline figure. */
+typedef struct msfl_timing {
+  int    launches_assoc;   double ms_assoc;     /* kNN + line/plane fit kernel        */
+  int    launches_solve;   double ms_solve;     /* persistent LM + Huber solve kernel */
+  int    launches_index;   double ms_index;     /* map grid index build (all kernels) */
+  int    launches_extract; double ms_extract;   /* feature extraction (all kernels)   */
+  int    launches_odom;    double ms_odom;      /* scan-to-scan association kernel    */
+} msfl_timing;
+
+/* ------------------------------------------------------------------------------------------ */
+/* lifecycle                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Fill `p` with the reference constants listed above. */
+void msfl_default_params(msfl_params* p);
+
+int msfl_api_version(void);
+
+/* Replaces construction of the matcher objects (laser_odometry.cc:56, laser_mapping.cc:42).
+   `params` may be NULL (defaults).  `device` is the HIP device ordinal. */
+msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out);
+void msfl_destroy(msfl_handle* h);
+
+/* Run all work of this handle on a caller-provided hipStream_t (e.g. torch's current stream);
+   NULL restores the handle's own stream. */
+msfl_status msfl_set_stream(msfl_handle* h, void* hip_stream);
+/* Block until everything queued by this handle has finished. */
+msfl_status msfl_synchronize(msfl_handle* h);
+
+const char* msfl_status_string(int status);
+/* Human-readable detail of the last non-OK status on this handle ("" if none). */
+const char* msfl_last_error(const msfl_handle* h);
+
+msfl_status msfl_set_timing(msfl_handle* h, int enabled);
+msfl_status msfl_get_timing(msfl_handle* h, msfl_timing* out, int reset);
+
+/* ------------------------------------------------------------------------------------------ */
+/* stage C — scan-to-local-map registration                                                   */
+/*   replaces MappingScanMatcher::MatchScan2Map (mapping_scan_matcher.h:14-21, .cc:19-278),    */
+/*   LiDAR-only branch (!is_initialized, .cc:96,123,168-171,193,238-241,271).                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Replaces the two pcl::KdTreeFLANN::setInputCloud calls (mapping_scan_matcher.cc:66-73):
+   uploads (if host) and spatially indexes cloud_map.cloud_corner_less_sharp /
+   cloud_map.cloud_surf_less_flat.  The index is an exact-kNN uniform grid.
+   The map stays resident until the next msfl_set_map on this handle. */
+msfl_status msfl_set_map(msfl_handle* h,
+                         const msfl_point* corner, int n_corner,
+                         const msfl_point* surf, int n_surf,
+                         msfl_mem mem);
+
+/* One registration against the resident map.
+     corner/surf : scan_curr.cloud_corner_less_sharp / cloud_surf_less_flat (already voxel
+                   down-sampled by the caller, laser_mapping.cc:264-270), scan frame.
+     pose_io     : pose_estimate_map_scan2world, Vector7, in = guess, out = result.
+     info        : optional diagnostics.
+   Returns MSFL_OK (the reference always returns true, .cc:277) or an error status; with zero
+   accepted correspondences the pose is returned unchanged (Ceres solves an empty problem). */
+msfl_status msfl_match_scan2map(msfl_handle* h,
+                                const msfl_point* corner, int n_corner,
+                                const msfl_point* surf, int n_surf,
+                                double pose_io[7], msfl_match_info* info,
+                                msfl_mem mem);
+
+/* B independent registrations against the same resident map in one call (the shape the
+   north-star batches: "many scans shard embarrassingly").
+     corner, corner_off : concatenated corner features and B+1 prefix offsets (scan b owns
+                          [corner_off[b], corner_off[b+1]) ); same for surf.
+     poses_io           : B x 7 doubles, in/out.
+     status             : B ints out (msfl_status per scan), may be NULL.
+     info               : B msfl_match_info out, may be NULL (host memory only).
+   With mem == MSFL_MEM_DEVICE all five arrays and poses_io/status are device pointers and the
+   call is asynchronous on the handle's stream. */
+msfl_status msfl_match_scan2map_batch(msfl_handle* h, int n_scans,
+                                      const msfl_point* corner, const int* corner_off,
+                                      const msfl_point* surf, const int* surf_off,
+                                      double* poses_io, int* status, msfl_match_info* info,
+                                      msfl_mem mem);
+
+/* Optional IMU-deskew inputs for the is_initialized branch (mapping_scan_matcher.cc:84-94,
+   119-121,154-166,189-191,224-236).  The per-point (delta_q, delta_p) = GetDeltaQP(preintegration,
+   dt) (scan_undistortion.cc:22-42) are computed by the caller (IMU pre-integration is outside the
+   hot path); the velocity block is held constant by the reference (.cc:94), so only the pose is
+   optimised.  Layout: delta_q as [qx qy qz qw], one per corner then one per surf feature. */
+typedef struct msfl_deskew {
+  const double* corner_dq;  /* n_corner x 4 */
+  const double* corner_dp;  /* n_corner x 3 */
+  const double* surf_dq;    /* n_surf x 4 */
+  const double* surf_dp;    /* n_surf x 3 */
+  double velocity[3];       /* bias_j.head<3>() (Vi, .cc:107) */
+  double gravity[3];        /* gravity_vector */
+} msfl_deskew;
+
+/* As msfl_match_scan2map with the Deskew factors (lidar_factor.cc:46-100).  Host pointers only. */
+msfl_status msfl_match_scan2map_deskew(msfl_handle* h,
+                                       const msfl_point* corner, int n_corner,
+                                       const msfl_point* surf, int n_surf,
+                                       const msfl_deskew* deskew,
+                                       double pose_io[7], msfl_match_info* info);
+
+/* ------------------------------------------------------------------------------------------ */
+/* stage B — scan-to-scan registration                                                        */
+/*   replaces OdometryScanMatcher::MatchScan2Scan (odometry_scan_matcher.h:10-12, .cc:43-285)  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* A ring-ordered feature cloud of PointXYZIRT (common.h:44-62): points + ring ids. */
+typedef struct msfl_ring_cloud {
+  const msfl_point* pts;
+  const uint16_t*   ring;
+  int               n;
+} msfl_ring_cloud;
+
+/*   last_less_sharp / last_less_flat : scan_last.cloud_corner_less_sharp / cloud_surf_less_flat
+     curr_sharp / curr_flat           : scan_curr.cloud_corner_sharp / cloud_surf_flat
+     pose_io                          : pose_estimate_curr2last, in/out.
+   Returns MSFL_TOO_FEW_CORRESPONDENCES where the reference returns false (.cc:262-267); the
+   pose then holds the result of the outer iterations completed so far. */
+msfl_status msfl_match_scan2scan(msfl_handle* h,
+                                 const msfl_ring_cloud* last_less_sharp,
+                                 const msfl_ring_cloud* last_less_flat,
+                                 const msfl_ring_cloud* curr_sharp,
+                                 const msfl_ring_cloud* curr_flat,
+                                 double pose_io[7], msfl_match_info* info,
+                                 msfl_mem mem);
+
+/* B independent (last, curr) pairs.  Each of the four feature sets is concatenated over the
+   batch with B+1 prefix offsets. */
+typedef struct msfl_ring_cloud_batch {
+  const msfl_point* pts;
+  const uint16_t*   ring;
+  const int*        off;   /* n_scans + 1 */
+} msfl_ring_cloud_batch;
+
+msfl_status msfl_match_scan2scan_batch(msfl_handle* h, int n_scans,
+                                       const msfl_ring_cloud_batch* last_less_sharp,
+                                       const msfl_ring_cloud_batch* last_less_flat,
+                                       const msfl_ring_cloud_batch* curr_sharp,
+                                       const msfl_ring_cloud_batch* curr_flat,
+                                       double* poses_io, int* status, msfl_match_info* info,
+                                       msfl_mem mem);
+
+/* ------------------------------------------------------------------------------------------ */
+/* stage A — feature extraction                                                               */
+/*   replaces RealHandleLaserCloudMessage (msf_loam_node.cc:160-378) between pcl::fromROSMsg   */
+/*   (:166-167) and LaserOdometry::AddLaserScan (:373).                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Output of one extraction = the five clouds of TimestampedPointCloud<PointXYZIRT>
+   (timestamped_pointcloud.h:11-42).  cloud_full_res is the ring-concatenated valid cloud
+   (msf_loam_node.cc:188-195) with t = relative time; the four feature clouds are returned as
+   INDEX LISTS into cloud_full_res (the reference push_back()s copies of those same points), in
+   the reference's push order.  Caller allocates: full_pts/full_ring/curvature/label with capacity
+   n_in, the four index arrays with capacity n_in each.  `extrinsic` (lidar->imu, :367-371) may be
+   NULL = identity (the shipped config, config/lio-sam-config2.json:7-20). */
+typedef struct msfl_features {
+  msfl_point* full_pts;    /* out: n_full points */
+  uint16_t*   full_ring;   /* out */
+  float*      curvature;   /* out: cloud_curvatures (valid for i in [5, n_full-5)) */
+  uint8_t*    label;       /* out: PointLabel 0 UNKNOWN 1 SHARP 2 LESS_SHARP 3 FLAT (:68-77) */
+  int*        sharp_idx;       /* out */
+  int*        less_sharp_idx;  /* out */
+  int*        flat_idx;        /* out */
+  int*        less_flat_idx;   /* out */
+  int n_full, n_sharp, n_less_sharp, n_flat, n_less_flat;  /* out counts */
+} msfl_features;
+
+/*   pts/ring : the sensor cloud as pcl::fromROSMsg delivers it (driver order), n points.
+   Returns MSFL_BAD_RING for ring >= 128 (CHECK at :136) and MSFL_BAD_ARG for an empty valid
+   cloud (CHECK at :186,200). */
+msfl_status msfl_extract_features(msfl_handle* h,
+                                  const msfl_point* pts, const uint16_t* ring, int n,
+                                  const double* extrinsic_pose7,
+                                  msfl_features* out, msfl_mem mem);
+
+/* B scans in one call; scan b owns [off[b], off[b+1]) of pts/ring and writes its outputs at the
+   same offsets of the out arrays (index lists are scan-local); counts go to the five
+   n_* arrays of length B. */
+typedef struct msfl_features_batch {
+  msfl_point* full_pts;  uint16_t* full_ring;  float* curvature;  uint8_t* label;
+  int* sharp_idx;  int* less_sharp_idx;  int* flat_idx;  int* less_flat_idx;
+  int* n_full;  int* n_sharp;  int* n_less_sharp;  int* n_flat;  int* n_less_flat;  /* B each */
+} msfl_features_batch;
+
+msfl_status msfl_extract_features_batch(msfl_handle* h, int n_scans,
+                                        const msfl_point* pts, const uint16_t* ring,
+                                        const int* off,
+                                        msfl_features_batch* out, int* status, msfl_mem mem);
+
+/* ------------------------------------------------------------------------------------------ */
+/* helpers on the caller side of the path: pcl::VoxelGrid down-sampling of  */
+/* the scan features before MatchScan2Map (laser_mapping.cc:264-270).                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Centroid voxel filter with PCL VoxelGrid semantics (leaf cube, centroid of x,y,z,t per
+   occupied voxel, output ordered by voxel index).  out has capacity n; *n_out receives the
+   count. */
+msfl_status msfl_voxel_downsample(msfl_handle* h,
+                                  const msfl_point* pts, int n, float leaf,
+                                  msfl_point* out, int* n_out, msfl_mem mem);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* MSFL_C_API_H_ */
