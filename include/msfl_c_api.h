@@ -195,6 +195,23 @@ msfl_status msfl_match_scan2map_batch(msfl_handle* h, int n_scans,
                                       double* poses_io, int* status, msfl_match_info* info,
                                       msfl_mem mem);
 
+/* Kernel-level entry points (the two halves of one outer iteration), exposed so that parity tests
+   can pin the data association and the solver separately:
+     msfl_associate_scan2map : mapping_scan_matcher.cc:109-246 at a fixed pose.  records_out gets
+                               (n_corner + n_surf) x 6 doubles {C[3], N[3]} in feature order (corner
+                               first); a rejected feature is all zeros.  For an edge C = point_a and
+                               N = (a-b).normalized() (:150-158); for a plane C = center, N = norm (:238).
+     msfl_solve_records      : one ceres::Solve (:250-259) on caller-provided records.
+   Host pointers only. */
+msfl_status msfl_associate_scan2map(msfl_handle* h,
+                                    const msfl_point* corner, int n_corner,
+                                    const msfl_point* surf, int n_surf,
+                                    const double pose[7], double* records_out);
+msfl_status msfl_solve_records(msfl_handle* h,
+                               const msfl_point* corner, int n_corner,
+                               const msfl_point* surf, int n_surf,
+                               const double* records, double pose_io[7], msfl_match_info* info);
+
 /* Optional IMU-deskew inputs for the is_initialized branch (mapping_scan_matcher.cc:84-94,
    119-121,154-166,189-191,224-236).  The per-point (delta_q, delta_p) = GetDeltaQP(preintegration,
    dt) (scan_undistortion.cc:22-42) are computed by the caller (IMU pre-integration is outside the

@@ -1,0 +1,350 @@
+"""ctypes binding of the C ABI (include/msfl_c_api.h) exported by msf_loam_amd/libmsfl_hip.so.
+
+This is plumbing for the Python harness (tests, bench.py).  It never falls back to a CPU path:
+if the shared library is missing or a call fails, it raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsfl_hip.so")
+
+OK, TOO_FEW_CORRESPONDENCES, MAP_TOO_SMALL, BAD_ARG, HIP_ERROR, BAD_RING, NO_MAP, CAPACITY = range(8)
+MEM_HOST, MEM_DEVICE = 0, 1
+
+EXPORTED = [
+    "msfl_default_params", "msfl_api_version", "msfl_create", "msfl_destroy", "msfl_set_stream",
+    "msfl_synchronize", "msfl_status_string", "msfl_last_error", "msfl_set_timing", "msfl_get_timing",
+    "msfl_set_map", "msfl_match_scan2map", "msfl_match_scan2map_batch", "msfl_match_scan2map_deskew",
+    "msfl_associate_scan2map", "msfl_solve_records",
+    "msfl_match_scan2scan", "msfl_match_scan2scan_batch", "msfl_extract_features",
+    "msfl_extract_features_batch", "msfl_voxel_downsample",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("scan_period", C.c_double), ("min_range", C.c_double),
+        ("curvature_threshold", C.c_float), ("neighbor_gap_sq", C.c_float),
+        ("sectors_per_ring", C.c_int), ("max_sharp_per_sector", C.c_int),
+        ("max_less_sharp_per_sector", C.c_int), ("max_flat_per_sector", C.c_int),
+        ("odom_distance_sq_threshold", C.c_double), ("odom_nearby_scan", C.c_double),
+        ("odom_min_correspondences", C.c_int),
+        ("map_knn", C.c_int), ("map_knn_max_sq_dist", C.c_float),
+        ("line_eigen_ratio", C.c_double), ("plane_tolerance", C.c_double),
+        ("outer_iterations", C.c_int), ("max_lm_iterations", C.c_int), ("huber_delta", C.c_double),
+        ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double), ("max_consecutive_invalid_steps", C.c_int),
+    ]
+
+
+class MatchInfo(C.Structure):
+    _fields_ = [("status", C.c_int), ("n_edge", C.c_int * 2), ("n_plane", C.c_int * 2),
+                ("lm_iterations", C.c_int * 2), ("lm_successful", C.c_int * 2),
+                ("initial_cost", C.c_double * 2), ("final_cost", C.c_double * 2)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("launches_assoc", C.c_int), ("ms_assoc", C.c_double),
+                ("launches_solve", C.c_int), ("ms_solve", C.c_double),
+                ("launches_index", C.c_int), ("ms_index", C.c_double),
+                ("launches_extract", C.c_int), ("ms_extract", C.c_double),
+                ("launches_odom", C.c_int), ("ms_odom", C.c_double)]
+
+
+class Deskew(C.Structure):
+    _fields_ = [("corner_dq", C.c_void_p), ("corner_dp", C.c_void_p), ("surf_dq", C.c_void_p),
+                ("surf_dp", C.c_void_p), ("velocity", C.c_double * 3), ("gravity", C.c_double * 3)]
+
+
+class RingCloud(C.Structure):
+    _fields_ = [("pts", C.c_void_p), ("ring", C.c_void_p), ("n", C.c_int)]
+
+
+class RingCloudBatch(C.Structure):
+    _fields_ = [("pts", C.c_void_p), ("ring", C.c_void_p), ("off", C.c_void_p)]
+
+
+class Features(C.Structure):
+    _fields_ = [("full_pts", C.c_void_p), ("full_ring", C.c_void_p), ("curvature", C.c_void_p),
+                ("label", C.c_void_p), ("sharp_idx", C.c_void_p), ("less_sharp_idx", C.c_void_p),
+                ("flat_idx", C.c_void_p), ("less_flat_idx", C.c_void_p),
+                ("n_full", C.c_int), ("n_sharp", C.c_int), ("n_less_sharp", C.c_int),
+                ("n_flat", C.c_int), ("n_less_flat", C.c_int)]
+
+
+class FeaturesBatch(C.Structure):
+    _fields_ = [("full_pts", C.c_void_p), ("full_ring", C.c_void_p), ("curvature", C.c_void_p),
+                ("label", C.c_void_p), ("sharp_idx", C.c_void_p), ("less_sharp_idx", C.c_void_p),
+                ("flat_idx", C.c_void_p), ("less_flat_idx", C.c_void_p),
+                ("n_full", C.c_void_p), ("n_sharp", C.c_void_p), ("n_less_sharp", C.c_void_p),
+                ("n_flat", C.c_void_p), ("n_less_flat", C.c_void_p)]
+
+
+class MsflError(RuntimeError):
+    def __init__(self, status, what, detail=""):
+        self.status = status
+        super().__init__(f"{what}: status {status} ({status_string(status)}) {detail}")
+
+
+_lib = None
+
+
+def load():
+    """Load libmsfl_hip.so.  Raises (never falls back) if the HIP extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        lib.msfl_status_string.restype = C.c_char_p
+        lib.msfl_last_error.restype = C.c_char_p
+        lib.msfl_last_error.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def status_string(s):
+    return load().msfl_status_string(C.c_int(int(s))).decode()
+
+
+def default_params():
+    p = Params()
+    load().msfl_default_params(C.byref(p))
+    return p
+
+
+def _vp(x):
+    """numpy array / int device pointer / torch tensor / None -> c_void_p"""
+    if x is None:
+        return C.c_void_p(None)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if isinstance(x, np.ndarray):
+        return C.c_void_p(x.ctypes.data)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    raise TypeError(type(x))
+
+
+def _pts(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1, 4))
+
+
+class Handle:
+    """Owns one msfl_handle (one HIP stream + device scratch)."""
+
+    def __init__(self, device=0, params=None):
+        self.lib = load()
+        self.h = C.c_void_p()
+        s = self.lib.msfl_create(C.byref(params) if params is not None else None, C.c_int(device), C.byref(self.h))
+        if s != OK:
+            raise MsflError(s, "msfl_create", "(no GPU / HIP runtime? there is no CPU fallback)")
+
+    def close(self):
+        if self.h:
+            self.lib.msfl_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, s, what, allow=()):
+        if s != OK and s not in allow:
+            raise MsflError(s, what, self.lib.msfl_last_error(self.h).decode())
+        return s
+
+    # ---- plumbing ----
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.msfl_set_stream(self.h, C.c_void_p(stream_ptr)), "msfl_set_stream")
+
+    def synchronize(self):
+        self._check(self.lib.msfl_synchronize(self.h), "msfl_synchronize")
+
+    def set_timing(self, on=True):
+        self._check(self.lib.msfl_set_timing(self.h, C.c_int(int(on))), "msfl_set_timing")
+
+    def get_timing(self, reset=True):
+        t = Timing()
+        self._check(self.lib.msfl_get_timing(self.h, C.byref(t), C.c_int(int(reset))), "msfl_get_timing")
+        return t
+
+    # ---- stage C ----
+    def set_map(self, corner, surf, n_corner=None, n_surf=None, mem=MEM_HOST):
+        if mem == MEM_HOST:
+            corner, surf = _pts(corner), _pts(surf)
+            n_corner, n_surf = len(corner), len(surf)
+            self._keep = (corner, surf)
+        self._check(self.lib.msfl_set_map(self.h, _vp(corner), C.c_int(n_corner), _vp(surf), C.c_int(n_surf),
+                                          C.c_int(mem)), "msfl_set_map")
+
+    def match_scan2map(self, corner, surf, pose, want_info=True, allow=()):
+        corner, surf = _pts(corner), _pts(surf)
+        pose = np.array(pose, dtype=np.float64)
+        info = MatchInfo()
+        s = self.lib.msfl_match_scan2map(self.h, _vp(corner), C.c_int(len(corner)), _vp(surf), C.c_int(len(surf)),
+                                         _vp(pose), C.byref(info) if want_info else None, C.c_int(MEM_HOST))
+        self._check(s, "msfl_match_scan2map", allow)
+        return s, pose, info
+
+    def match_scan2map_batch(self, corner, corner_off, surf, surf_off, poses, want_info=False):
+        """Host-memory batch. Returns (poses (B,7), status (B,), info list or None)."""
+        corner, surf = _pts(corner), _pts(surf)
+        co = np.ascontiguousarray(corner_off, dtype=np.int32)
+        so = np.ascontiguousarray(surf_off, dtype=np.int32)
+        poses = np.array(poses, dtype=np.float64).reshape(-1, 7).copy()
+        B = len(poses)
+        status = np.zeros(B, np.int32)
+        info = (MatchInfo * B)() if want_info else None
+        s = self.lib.msfl_match_scan2map_batch(self.h, C.c_int(B), _vp(corner), _vp(co), _vp(surf), _vp(so), _vp(poses),
+                                               _vp(status), info, C.c_int(MEM_HOST))
+        self._check(s, "msfl_match_scan2map_batch")
+        return poses, status, info
+
+    def match_scan2map_batch_device(self, B, corner_ptr, corner_off, surf_ptr, surf_off, poses_ptr, status_ptr=None):
+        """Device-resident batch (asynchronous on the handle's stream). Offsets are host arrays."""
+        co = np.ascontiguousarray(corner_off, dtype=np.int32)
+        so = np.ascontiguousarray(surf_off, dtype=np.int32)
+        s = self.lib.msfl_match_scan2map_batch(self.h, C.c_int(B), _vp(corner_ptr), _vp(co), _vp(surf_ptr), _vp(so),
+                                               _vp(poses_ptr), _vp(status_ptr), None, C.c_int(MEM_DEVICE))
+        self._check(s, "msfl_match_scan2map_batch(device)")
+
+    def associate_scan2map(self, corner, surf, pose):
+        """One data-association pass at `pose`: (n_corner+n_surf, 6) records {C, N}."""
+        corner, surf = _pts(corner), _pts(surf)
+        rec = np.zeros((max(len(corner) + len(surf), 1), 6))
+        pose = np.ascontiguousarray(pose, dtype=np.float64)
+        self._check(self.lib.msfl_associate_scan2map(self.h, _vp(corner), C.c_int(len(corner)), _vp(surf),
+                                                     C.c_int(len(surf)), _vp(pose), _vp(rec)), "msfl_associate_scan2map")
+        return rec[:len(corner) + len(surf)]
+
+    def solve_records(self, corner, surf, records, pose):
+        corner, surf = _pts(corner), _pts(surf)
+        rec = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 6)
+        pose = np.array(pose, dtype=np.float64)
+        info = MatchInfo()
+        self._check(self.lib.msfl_solve_records(self.h, _vp(corner), C.c_int(len(corner)), _vp(surf), C.c_int(len(surf)),
+                                                _vp(rec), _vp(pose), C.byref(info)), "msfl_solve_records")
+        return pose, info
+
+    def match_scan2map_deskew(self, corner, surf, corner_dq, corner_dp, surf_dq, surf_dp, velocity, gravity, pose):
+        corner, surf = _pts(corner), _pts(surf)
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (corner_dq, corner_dp, surf_dq, surf_dp)]
+        d = Deskew()
+        d.corner_dq, d.corner_dp, d.surf_dq, d.surf_dp = (a.ctypes.data for a in arrs)
+        d.velocity = (C.c_double * 3)(*velocity)
+        d.gravity = (C.c_double * 3)(*gravity)
+        pose = np.array(pose, dtype=np.float64)
+        info = MatchInfo()
+        s = self.lib.msfl_match_scan2map_deskew(self.h, _vp(corner), C.c_int(len(corner)), _vp(surf), C.c_int(len(surf)),
+                                                C.byref(d), _vp(pose), C.byref(info))
+        self._check(s, "msfl_match_scan2map_deskew")
+        return s, pose, info
+
+    # ---- stage B ----
+    def match_scan2scan(self, last_ls, last_ls_ring, last_lf, last_lf_ring, sharp, flat, pose, allow=(TOO_FEW_CORRESPONDENCES,)):
+        clouds = []
+        keep = []
+        for pts, ring in ((last_ls, last_ls_ring), (last_lf, last_lf_ring), (sharp, None), (flat, None)):
+            p = _pts(pts)
+            r = np.ascontiguousarray(ring if ring is not None else np.zeros(len(p)), dtype=np.uint16)
+            keep.append((p, r))
+            rc = RingCloud()
+            rc.pts, rc.ring, rc.n = p.ctypes.data, r.ctypes.data, len(p)
+            clouds.append(rc)
+        pose = np.array(pose, dtype=np.float64)
+        info = MatchInfo()
+        s = self.lib.msfl_match_scan2scan(self.h, C.byref(clouds[0]), C.byref(clouds[1]), C.byref(clouds[2]),
+                                          C.byref(clouds[3]), _vp(pose), C.byref(info), C.c_int(MEM_HOST))
+        self._check(s, "msfl_match_scan2scan", allow)
+        return s, pose, info
+
+    def match_scan2scan_batch(self, clouds, poses, want_info=False):
+        """clouds: 4 tuples (pts (n,4), ring (n,), off (B+1,)) for last_less_sharp, last_less_flat,
+        curr_sharp, curr_flat (ring may be None for the curr sets)."""
+        structs, keep = [], []
+        for pts, ring, off in clouds:
+            p = _pts(pts)
+            r = np.ascontiguousarray(ring if ring is not None else np.zeros(len(p)), dtype=np.uint16)
+            o = np.ascontiguousarray(off, dtype=np.int32)
+            keep.append((p, r, o))
+            rb = RingCloudBatch()
+            rb.pts, rb.ring, rb.off = p.ctypes.data, r.ctypes.data, o.ctypes.data
+            structs.append(rb)
+        poses = np.array(poses, dtype=np.float64).reshape(-1, 7).copy()
+        B = len(poses)
+        status = np.zeros(B, np.int32)
+        info = (MatchInfo * B)() if want_info else None
+        s = self.lib.msfl_match_scan2scan_batch(self.h, C.c_int(B), C.byref(structs[0]), C.byref(structs[1]),
+                                                C.byref(structs[2]), C.byref(structs[3]), _vp(poses), _vp(status), info,
+                                                C.c_int(MEM_HOST))
+        self._check(s, "msfl_match_scan2scan_batch")
+        return poses, status, info
+
+    # ---- stage A ----
+    def extract_features(self, pts, ring, extrinsic=None, allow=()):
+        pts = _pts(pts)
+        ring = np.ascontiguousarray(ring, dtype=np.uint16)
+        n = max(len(pts), 1)
+        out = dict(full=np.zeros((n, 4), np.float32), ring=np.zeros(n, np.uint16), curvature=np.zeros(n, np.float32),
+                   label=np.zeros(n, np.uint8), sharp=np.zeros(n, np.int32), less_sharp=np.zeros(n, np.int32),
+                   flat=np.zeros(n, np.int32), less_flat=np.zeros(n, np.int32))
+        f = Features()
+        f.full_pts, f.full_ring, f.curvature, f.label = (out[k].ctypes.data for k in ("full", "ring", "curvature", "label"))
+        f.sharp_idx, f.less_sharp_idx, f.flat_idx, f.less_flat_idx = (out[k].ctypes.data for k in ("sharp", "less_sharp", "flat", "less_flat"))
+        ext = np.ascontiguousarray(extrinsic, dtype=np.float64) if extrinsic is not None else None
+        s = self.lib.msfl_extract_features(self.h, _vp(pts), _vp(ring), C.c_int(len(pts)), _vp(ext), C.byref(f), C.c_int(MEM_HOST))
+        self._check(s, "msfl_extract_features", allow)
+        nf = f.n_full
+        return dict(rc=s, full=out["full"][:nf], ring=out["ring"][:nf], curvature=out["curvature"][:nf],
+                    label=out["label"][:nf], sharp=out["sharp"][:f.n_sharp].copy(),
+                    less_sharp=out["less_sharp"][:f.n_less_sharp].copy(), flat=out["flat"][:f.n_flat].copy(),
+                    less_flat=out["less_flat"][:f.n_less_flat].copy())
+
+    def extract_features_batch(self, pts, ring, off):
+        """Host-memory batch.  Returns a list of per-scan dicts like extract_features()."""
+        pts = _pts(pts)
+        ring = np.ascontiguousarray(ring, dtype=np.uint16)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        B = len(off) - 1
+        n = max(len(pts), 1)
+        out = dict(full=np.zeros((n, 4), np.float32), ring=np.zeros(n, np.uint16), curvature=np.zeros(n, np.float32),
+                   label=np.zeros(n, np.uint8), sharp=np.zeros(n, np.int32), less_sharp=np.zeros(n, np.int32),
+                   flat=np.zeros(n, np.int32), less_flat=np.zeros(n, np.int32))
+        cnt = {k: np.zeros(max(B, 1), np.int32) for k in ("n_full", "n_sharp", "n_less_sharp", "n_flat", "n_less_flat")}
+        f = FeaturesBatch()
+        f.full_pts, f.full_ring, f.curvature, f.label = (out[k].ctypes.data for k in ("full", "ring", "curvature", "label"))
+        f.sharp_idx, f.less_sharp_idx, f.flat_idx, f.less_flat_idx = (out[k].ctypes.data for k in ("sharp", "less_sharp", "flat", "less_flat"))
+        f.n_full, f.n_sharp, f.n_less_sharp, f.n_flat, f.n_less_flat = (cnt[k].ctypes.data for k in ("n_full", "n_sharp", "n_less_sharp", "n_flat", "n_less_flat"))
+        status = np.zeros(max(B, 1), np.int32)
+        s = self.lib.msfl_extract_features_batch(self.h, C.c_int(B), _vp(pts), _vp(ring), _vp(off), C.byref(f), _vp(status),
+                                                 C.c_int(MEM_HOST))
+        self._check(s, "msfl_extract_features_batch")
+        res = []
+        for b in range(B):
+            o = int(off[b])
+            nf = int(cnt["n_full"][b])
+            res.append(dict(rc=int(status[b]), full=out["full"][o:o + nf], ring=out["ring"][o:o + nf],
+                            curvature=out["curvature"][o:o + nf], label=out["label"][o:o + nf],
+                            sharp=out["sharp"][o:o + cnt["n_sharp"][b]].copy(),
+                            less_sharp=out["less_sharp"][o:o + cnt["n_less_sharp"][b]].copy(),
+                            flat=out["flat"][o:o + cnt["n_flat"][b]].copy(),
+                            less_flat=out["less_flat"][o:o + cnt["n_less_flat"][b]].copy()))
+        return res
+
+    def voxel_downsample(self, pts, leaf):
+        pts = _pts(pts)
+        out = np.zeros((max(len(pts), 1), 4), np.float32)
+        n_out = C.c_int(0)
+        self._check(self.lib.msfl_voxel_downsample(self.h, _vp(pts), C.c_int(len(pts)), C.c_float(leaf), _vp(out),
+                                                   C.byref(n_out), C.c_int(MEM_HOST)), "msfl_voxel_downsample")
+        return out[:n_out.value].copy()

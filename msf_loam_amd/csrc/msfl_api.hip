@@ -1,0 +1,611 @@
+// msfl_api.hip — C-ABI implementation (include/msfl_c_api.h) over the HIP kernels.
+//
+// One handle = one HIP stream + all device scratch; no global state, so the reference's two
+// matcher instances (odometry thread / mapping thread) map to two independent handles.
+// There is NO CPU fallback: every entry point either runs the gfx950 kernels or returns an
+// error status.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/msfl_c_api.h"
+#include "msfl_kernels.cuh"
+#include "msfl_extract.cuh"
+#include "msfl_odom.cuh"
+
+using namespace msfl;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    size_t want = std::max(bytes, cap + cap / 2);
+    want = (want + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct MapIndex {
+  GridDesc g{};
+  DevBuf sorted;      // float4[n]
+  DevBuf cell_start;  // int[n_cells + 1]
+  int n_input = 0;    // points handed to msfl_set_map
+};
+
+enum TimerClass { T_ASSOC = 0, T_SOLVE, T_INDEX, T_EXTRACT, T_ODOM, T_COUNT };
+
+struct TimedSpan { hipEvent_t a, b; int cls; };
+
+}  // namespace
+
+struct msfl_handle_s {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  msfl_params prm{};
+  std::string last_error;
+
+  bool have_map = false;
+  MapIndex map_c, map_s;
+
+  // scratch
+  DevBuf in_corner, in_surf, in_off, poses, status, info, records, pprime;
+  DevBuf idx_cell_of, idx_count, idx_bbox, idx_cub, idx_stage;
+  DevBuf dk[4];
+  DevBuf ex[16];
+  DevBuf od[16];
+
+  // timing
+  bool timing = false;
+  std::vector<TimedSpan> spans;
+  std::vector<hipEvent_t> free_events;
+  double t_ms[T_COUNT] = {0};
+  int t_n[T_COUNT] = {0};
+};
+
+namespace {
+
+msfl_status fail(msfl_handle* h, msfl_status s, const std::string& msg) {
+  if (h) h->last_error = msg;
+  return s;
+}
+
+#define HIPCHK(h, expr)                                                                            \
+  do {                                                                                             \
+    hipError_t e__ = (expr);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return fail(h, MSFL_HIP_ERROR, std::string(#expr) + ": " + hipGetErrorString(e__));          \
+  } while (0)
+
+hipEvent_t get_event(msfl_handle* h) {
+  if (!h->free_events.empty()) { hipEvent_t e = h->free_events.back(); h->free_events.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct ScopedTimer {
+  msfl_handle* h; TimedSpan s{}; bool on;
+  ScopedTimer(msfl_handle* h_, int cls) : h(h_), on(h_->timing) {
+    if (on) { s.a = get_event(h); s.b = get_event(h); s.cls = cls; (void)hipEventRecord(s.a, h->stream); }
+  }
+  ~ScopedTimer() {
+    if (on) { (void)hipEventRecord(s.b, h->stream); h->spans.push_back(s); }
+  }
+};
+
+void collect_timing(msfl_handle* h) {
+  for (auto& s : h->spans) {
+    (void)hipEventSynchronize(s.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { h->t_ms[s.cls] += ms; h->t_n[s.cls]++; }
+    h->free_events.push_back(s.a); h->free_events.push_back(s.b);
+  }
+  h->spans.clear();
+}
+
+SolverParams solver_params(const msfl_params& p, int min_corr) {
+  SolverParams s;
+  s.max_iterations = p.max_lm_iterations;
+  s.huber = p.huber_delta;
+  s.radius0 = p.initial_trust_region_radius;
+  s.radius_max = p.max_trust_region_radius;
+  s.radius_min = p.min_trust_region_radius;
+  s.min_relative_decrease = p.min_relative_decrease;
+  s.min_diag = p.min_lm_diagonal;
+  s.max_diag = p.max_lm_diagonal;
+  s.ftol = p.function_tolerance;
+  s.gtol = p.gradient_tolerance;
+  s.ptol = p.parameter_tolerance;
+  s.max_invalid = p.max_consecutive_invalid_steps;
+  s.min_correspondences = min_corr;
+  return s;
+}
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// Build the exact-kNN grid over `pts` (device pointer, n points).
+msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) {
+  ScopedTimer timer(h, T_INDEX);
+  mi.n_input = n;
+  mi.g = GridDesc{};
+  if (n <= 0) return MSFL_OK;
+  hipStream_t st = h->stream;
+  HIPCHK(h, h->idx_bbox.reserve(6 * sizeof(int)));
+  int init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
+  HIPCHK(h, hipMemcpyAsync(h->idx_bbox.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+  const int blocks = std::min(div_up(n, 256), 2048);
+  hipLaunchKernelGGL(grid_bbox_kernel, dim3(blocks), dim3(256), 0, st, pts, n, h->idx_bbox.as<int>());
+  int bb[6];
+  HIPCHK(h, hipMemcpyAsync(bb, h->idx_bbox.p, sizeof(bb), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (bb[0] == INT32_MAX) return MSFL_OK;   // no finite point
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; a++) { mn[a] = ordered_to_float(bb[a]); mx[a] = ordered_to_float(bb[3 + a]); }
+  // cell edge: >= 1.001 * acceptance radius (rigorous exactness under f32 rounding of the cell
+  // coordinate); grown if the dense table would exceed the cap (larger cells stay exact).
+  double cell = 1.001 * std::sqrt((double)h->prm.map_knn_max_sq_dist);
+  const double cap_cells = 64.0 * 1024 * 1024;
+  int dims[3];
+  for (;;) {
+    double total = 1.0;
+    for (int a = 0; a < 3; a++) {
+      dims[a] = (int)std::floor(((double)mx[a] - (double)mn[a]) / cell) + 1;
+      if (dims[a] < 1) dims[a] = 1;
+      total *= dims[a];
+    }
+    if (total <= cap_cells) break;
+    cell *= 1.26;
+  }
+  GridDesc g;
+  g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+  g.inv_cell = (float)(1.0 / cell);
+  // f32 rounding of (v - o) * inv may land exactly on dim: one spare cell per axis
+  g.dx = dims[0] + 1; g.dy = dims[1] + 1; g.dz = dims[2] + 1;
+  g.n_cells = g.dx * g.dy * g.dz;
+  g.n_pts = 0;
+  HIPCHK(h, h->idx_cell_of.reserve((size_t)n * sizeof(int)));
+  HIPCHK(h, h->idx_count.reserve(((size_t)g.n_cells + 1) * sizeof(int)));
+  HIPCHK(h, mi.cell_start.reserve(((size_t)g.n_cells + 1) * sizeof(int)));
+  HIPCHK(h, mi.sorted.reserve((size_t)n * sizeof(float4)));
+  HIPCHK(h, hipMemsetAsync(h->idx_count.p, 0, ((size_t)g.n_cells + 1) * sizeof(int), st));
+  hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, g, h->idx_cell_of.as<int>(),
+                     h->idx_count.as<int>());
+  size_t tmp_bytes = 0;
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(),
+                                             g.n_cells + 1, st));
+  HIPCHK(h, h->idx_cub.reserve(tmp_bytes));
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(h->idx_cub.p, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(),
+                                             g.n_cells + 1, st));
+  hipLaunchKernelGGL(grid_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, h->idx_cell_of.as<int>(),
+                     mi.cell_start.as<int>(), h->idx_count.as<int>(), mi.sorted.as<float4>());
+  HIPCHK(h, hipGetLastError());
+  // number of indexed (finite) points = cell_start[n_cells]; only needed for the < 5 gate
+  int total = 0;
+  HIPCHK(h, hipMemcpyAsync(&total, mi.cell_start.as<int>() + g.n_cells, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  g.n_pts = total;
+  mi.g = g;
+  return MSFL_OK;
+}
+
+// Core of stage C.  All pointers are device pointers except the offsets (host).
+msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner, const int* h_corner_off,
+                                  const float4* d_surf, const int* h_surf_off, double* d_poses, int* d_status,
+                                  DevMatchInfo* d_info, const DeskewView* deskew) {
+  hipStream_t st = h->stream;
+  // offsets -> device: [corner_off (B+1) | surf_off (B+1) | rec_off (B+1)]
+  std::vector<int> offs(3 * (size_t)(B + 1));
+  for (int b = 0; b <= B; b++) {
+    offs[b] = h_corner_off[b];
+    offs[(B + 1) + b] = h_surf_off[b];
+    offs[2 * (B + 1) + b] = h_corner_off[b] - h_corner_off[0] + h_surf_off[b] - h_surf_off[0];
+    if (b > 0 && (h_corner_off[b] < h_corner_off[b - 1] || h_surf_off[b] < h_surf_off[b - 1]))
+      return fail(h, MSFL_BAD_ARG, "offset arrays must be non-decreasing");
+  }
+  const int n_rec = offs[2 * (B + 1) + B];
+  HIPCHK(h, h->in_off.reserve(offs.size() * sizeof(int)));
+  HIPCHK(h, hipMemcpyAsync(h->in_off.p, offs.data(), offs.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  // the staging vector must outlive the async copy from pageable memory: hipMemcpyAsync from
+  // pageable host memory returns after the data has been staged, so this is safe.
+  HIPCHK(h, h->records.reserve(std::max<size_t>(1, (size_t)n_rec) * 6 * sizeof(double)));
+  BatchView bv;
+  bv.corner = d_corner; bv.corner_off = h->in_off.as<int>();
+  bv.surf = d_surf; bv.surf_off = h->in_off.as<int>() + (B + 1);
+  bv.rec_off = h->in_off.as<int>() + 2 * (B + 1);
+  bv.n_scans = B; bv.n_records = n_rec;
+  DeskewView dv{};
+  if (deskew) {
+    dv = *deskew;
+    HIPCHK(h, h->pprime.reserve(std::max<size_t>(1, (size_t)n_rec) * 3 * sizeof(double)));
+    dv.pprime = h->pprime.as<double>();
+  }
+  const SolverParams sp = solver_params(h->prm, 0);
+  for (int it = 0; it < h->prm.outer_iterations; it++) {
+    if (n_rec > 0) {
+      ScopedTimer timer(h, T_ASSOC);
+      if (deskew) {
+        hipLaunchKernelGGL(assoc_scan2map_kernel<true>, dim3(div_up(n_rec, 256)), dim3(256), 0, st, bv, d_poses, d_status,
+                           h->map_c.g, h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                           h->map_s.g, h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                           h->prm.map_knn_max_sq_dist, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
+                           h->records.as<double>());
+      } else {
+        hipLaunchKernelGGL(assoc_scan2map_kernel<false>, dim3(div_up(n_rec, 256)), dim3(256), 0, st, bv, d_poses, d_status,
+                           h->map_c.g, h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                           h->map_s.g, h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                           h->prm.map_knn_max_sq_dist, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
+                           h->records.as<double>());
+      }
+    }
+    {
+      ScopedTimer timer(h, T_SOLVE);
+      hipLaunchKernelGGL(lm_solve_kernel<256>, dim3(B), dim3(256), 0, st, bv,
+                         deskew ? (const double*)dv.pprime : (const double*)nullptr,
+                         (const double*)h->records.as<double>(), d_poses, d_status, d_info, it, sp);
+    }
+  }
+  HIPCHK(h, hipGetLastError());
+  return MSFL_OK;
+}
+
+msfl_status check_map(msfl_handle* h) {
+  if (!h->have_map) return fail(h, MSFL_NO_MAP, "msfl_set_map has not been called on this handle");
+  if (h->map_c.g.n_pts < 5 || h->map_s.g.n_pts < 5)
+    return fail(h, MSFL_MAP_TOO_SMALL, "map corner/surf cloud has fewer than 5 points (mapping_scan_matcher.cc:128,198 would read out of bounds)");
+  return MSFL_OK;
+}
+
+msfl_status enter(msfl_handle* h) {
+  if (!h) return MSFL_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  return MSFL_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// lifecycle
+// =============================================================================================
+
+extern "C" {
+
+void msfl_default_params(msfl_params* p) {
+  if (!p) return;
+  p->scan_period = 0.1;
+  p->min_range = 0.3;
+  p->curvature_threshold = 0.1f;
+  p->neighbor_gap_sq = 0.05f;
+  p->sectors_per_ring = 6;
+  p->max_sharp_per_sector = 2;
+  p->max_less_sharp_per_sector = 20;
+  p->max_flat_per_sector = 4;
+  p->odom_distance_sq_threshold = 25.0;
+  p->odom_nearby_scan = 2.5;
+  p->odom_min_correspondences = 10;
+  p->map_knn = 5;
+  p->map_knn_max_sq_dist = 1.0f;
+  p->line_eigen_ratio = 3.0;
+  p->plane_tolerance = 0.2;
+  p->outer_iterations = 2;
+  p->max_lm_iterations = 6;
+  p->huber_delta = 0.1;
+  p->initial_trust_region_radius = 1e4;
+  p->max_trust_region_radius = 1e16;
+  p->min_trust_region_radius = 1e-32;
+  p->min_relative_decrease = 1e-3;
+  p->min_lm_diagonal = 1e-6;
+  p->max_lm_diagonal = 1e32;
+  p->function_tolerance = 1e-6;
+  p->gradient_tolerance = 1e-10;
+  p->parameter_tolerance = 1e-8;
+  p->max_consecutive_invalid_steps = 5;
+}
+
+int msfl_api_version(void) { return MSFL_API_VERSION; }
+
+msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out) {
+  if (!out) return MSFL_BAD_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MSFL_HIP_ERROR;   // no GPU: fail loudly, no fallback
+  if (device < 0 || device >= ndev) return MSFL_BAD_ARG;
+  msfl_handle* h = new msfl_handle_s();
+  h->device = device;
+  if (params) h->prm = *params; else msfl_default_params(&h->prm);
+  if (h->prm.map_knn != 5 || h->prm.outer_iterations < 1 || h->prm.outer_iterations > 2 ||
+      h->prm.max_lm_iterations < 0 || !(h->prm.map_knn_max_sq_dist > 0.f) ||
+      h->prm.sectors_per_ring < 1 || h->prm.sectors_per_ring > 16) {
+    delete h;
+    return MSFL_BAD_ARG;
+  }
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return MSFL_HIP_ERROR;
+  }
+  h->stream = h->own_stream;
+  *out = h;
+  return MSFL_OK;
+}
+
+void msfl_destroy(msfl_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  collect_timing(h);
+  for (auto e : h->free_events) (void)hipEventDestroy(e);
+  DevBuf* bufs[] = {&h->map_c.sorted, &h->map_c.cell_start, &h->map_s.sorted, &h->map_s.cell_start, &h->in_corner,
+                    &h->in_surf, &h->in_off, &h->poses, &h->status, &h->info, &h->records, &h->pprime,
+                    &h->idx_cell_of, &h->idx_count, &h->idx_bbox, &h->idx_cub, &h->idx_stage};
+  for (auto* b : bufs) b->release();
+  for (auto& b : h->dk) b.release();
+  for (auto& b : h->ex) b.release();
+  for (auto& b : h->od) b.release();
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+msfl_status msfl_set_stream(msfl_handle* h, void* hip_stream) {
+  msfl_status s = enter(h); if (s) return s;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return MSFL_OK;
+}
+
+msfl_status msfl_synchronize(msfl_handle* h) {
+  msfl_status s = enter(h); if (s) return s;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MSFL_OK;
+}
+
+const char* msfl_status_string(int status) {
+  switch (status) {
+    case MSFL_OK: return "OK";
+    case MSFL_TOO_FEW_CORRESPONDENCES: return "TOO_FEW_CORRESPONDENCES";
+    case MSFL_MAP_TOO_SMALL: return "MAP_TOO_SMALL";
+    case MSFL_BAD_ARG: return "BAD_ARG";
+    case MSFL_HIP_ERROR: return "HIP_ERROR";
+    case MSFL_BAD_RING: return "BAD_RING";
+    case MSFL_NO_MAP: return "NO_MAP";
+    case MSFL_CAPACITY: return "CAPACITY";
+    default: return "UNKNOWN";
+  }
+}
+
+const char* msfl_last_error(const msfl_handle* h) { return h ? h->last_error.c_str() : ""; }
+
+msfl_status msfl_set_timing(msfl_handle* h, int enabled) {
+  msfl_status s = enter(h); if (s) return s;
+  h->timing = enabled != 0;
+  return MSFL_OK;
+}
+
+msfl_status msfl_get_timing(msfl_handle* h, msfl_timing* out, int reset) {
+  msfl_status s = enter(h); if (s) return s;
+  if (!out) return MSFL_BAD_ARG;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  out->launches_assoc = h->t_n[T_ASSOC];     out->ms_assoc = h->t_ms[T_ASSOC];
+  out->launches_solve = h->t_n[T_SOLVE];     out->ms_solve = h->t_ms[T_SOLVE];
+  out->launches_index = h->t_n[T_INDEX];     out->ms_index = h->t_ms[T_INDEX];
+  out->launches_extract = h->t_n[T_EXTRACT]; out->ms_extract = h->t_ms[T_EXTRACT];
+  out->launches_odom = h->t_n[T_ODOM];       out->ms_odom = h->t_ms[T_ODOM];
+  if (reset) for (int i = 0; i < T_COUNT; i++) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+  return MSFL_OK;
+}
+
+// =============================================================================================
+// stage C
+// =============================================================================================
+
+msfl_status msfl_set_map(msfl_handle* h, const msfl_point* corner, int n_corner, const msfl_point* surf, int n_surf,
+                         msfl_mem mem) {
+  msfl_status s = enter(h); if (s) return s;
+  if (n_corner < 0 || n_surf < 0 || (n_corner > 0 && !corner) || (n_surf > 0 && !surf))
+    return fail(h, MSFL_BAD_ARG, "msfl_set_map: null cloud with positive size");
+  h->have_map = false;
+  const float4* dc = reinterpret_cast<const float4*>(corner);
+  const float4* ds = reinterpret_cast<const float4*>(surf);
+  if (mem == MSFL_MEM_HOST) {
+    HIPCHK(h, h->idx_stage.reserve(std::max<size_t>(1, (size_t)n_corner + (size_t)n_surf) * sizeof(float4)));
+    float4* stage = h->idx_stage.as<float4>();
+    if (n_corner) HIPCHK(h, hipMemcpyAsync(stage, corner, (size_t)n_corner * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    if (n_surf) HIPCHK(h, hipMemcpyAsync(stage + n_corner, surf, (size_t)n_surf * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    dc = stage; ds = stage + n_corner;
+  }
+  s = build_index(h, dc, n_corner, h->map_c); if (s) return s;
+  s = build_index(h, ds, n_surf, h->map_s); if (s) return s;
+  h->have_map = true;
+  return MSFL_OK;
+}
+
+static msfl_status match_batch_impl(msfl_handle* h, int B, const msfl_point* corner, const int* corner_off,
+                                    const msfl_point* surf, const int* surf_off, double* poses_io, int* status,
+                                    msfl_match_info* info, msfl_mem mem, const msfl_deskew* deskew) {
+  if (B < 0 || (B > 0 && (!corner_off || !surf_off || !poses_io)))
+    return fail(h, MSFL_BAD_ARG, "msfl_match_scan2map_batch: null argument");
+  if (B == 0) return MSFL_OK;
+  msfl_status s = check_map(h); if (s) return s;
+  hipStream_t st = h->stream;
+  const int c0 = corner_off[0], s0 = surf_off[0];
+  const int ncp = corner_off[B] - c0, nsp = surf_off[B] - s0;
+  if (ncp < 0 || nsp < 0 || (ncp > 0 && !corner) || (nsp > 0 && !surf))
+    return fail(h, MSFL_BAD_ARG, "msfl_match_scan2map_batch: bad offsets or null feature array");
+  const float4* d_corner; const float4* d_surf; double* d_poses; int* d_status;
+  std::vector<int> co(corner_off, corner_off + B + 1), so(surf_off, surf_off + B + 1);
+  if (mem == MSFL_MEM_HOST) {
+    HIPCHK(h, h->in_corner.reserve(std::max<size_t>(1, (size_t)ncp) * sizeof(float4)));
+    HIPCHK(h, h->in_surf.reserve(std::max<size_t>(1, (size_t)nsp) * sizeof(float4)));
+    HIPCHK(h, h->poses.reserve((size_t)B * 7 * sizeof(double)));
+    if (ncp) HIPCHK(h, hipMemcpyAsync(h->in_corner.p, corner + c0, (size_t)ncp * sizeof(float4), hipMemcpyHostToDevice, st));
+    if (nsp) HIPCHK(h, hipMemcpyAsync(h->in_surf.p, surf + s0, (size_t)nsp * sizeof(float4), hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->poses.p, poses_io, (size_t)B * 7 * sizeof(double), hipMemcpyHostToDevice, st));
+    for (int b = 0; b <= B; b++) { co[b] -= c0; so[b] -= s0; }
+    d_corner = h->in_corner.as<float4>(); d_surf = h->in_surf.as<float4>(); d_poses = h->poses.as<double>();
+  } else {
+    d_corner = reinterpret_cast<const float4*>(corner); d_surf = reinterpret_cast<const float4*>(surf);
+    d_poses = poses_io;
+  }
+  if (mem == MSFL_MEM_DEVICE && status) {
+    d_status = status;
+  } else {
+    HIPCHK(h, h->status.reserve((size_t)B * sizeof(int)));
+    d_status = h->status.as<int>();
+  }
+  HIPCHK(h, hipMemsetAsync(d_status, 0, (size_t)B * sizeof(int), st));
+  DevMatchInfo* d_info = nullptr;
+  if (info) {
+    static_assert(sizeof(DevMatchInfo) == sizeof(msfl_match_info), "info layout");
+    HIPCHK(h, h->info.reserve((size_t)B * sizeof(DevMatchInfo)));
+    HIPCHK(h, hipMemsetAsync(h->info.p, 0, (size_t)B * sizeof(DevMatchInfo), st));
+    d_info = h->info.as<DevMatchInfo>();
+  }
+  DeskewView dv{}; const DeskewView* dvp = nullptr;
+  if (deskew) {
+    // host pointers only (documented); stage the four arrays
+    const size_t nb[4] = {(size_t)ncp * 4, (size_t)ncp * 3, (size_t)nsp * 4, (size_t)nsp * 3};
+    const double* src[4] = {deskew->corner_dq, deskew->corner_dp, deskew->surf_dq, deskew->surf_dp};
+    for (int k = 0; k < 4; k++) {
+      if (nb[k] && !src[k]) return fail(h, MSFL_BAD_ARG, "msfl_match_scan2map_deskew: null deskew array");
+      HIPCHK(h, h->dk[k].reserve(std::max<size_t>(1, nb[k]) * sizeof(double)));
+      if (nb[k]) HIPCHK(h, hipMemcpyAsync(h->dk[k].p, src[k], nb[k] * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    dv.corner_dq = h->dk[0].as<double>(); dv.corner_dp = h->dk[1].as<double>();
+    dv.surf_dq = h->dk[2].as<double>(); dv.surf_dp = h->dk[3].as<double>();
+    for (int a = 0; a < 3; a++) { dv.V[a] = deskew->velocity[a]; dv.G[a] = deskew->gravity[a]; }
+    dvp = &dv;
+  }
+  s = match_scan2map_device(h, B, d_corner, co.data(), d_surf, so.data(), d_poses, d_status, d_info, dvp);
+  if (s) return s;
+  if (mem == MSFL_MEM_HOST) {
+    HIPCHK(h, hipMemcpyAsync(poses_io, d_poses, (size_t)B * 7 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (status) HIPCHK(h, hipMemcpyAsync(status, d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  if (info) HIPCHK(h, hipMemcpyAsync(info, d_info, (size_t)B * sizeof(DevMatchInfo), hipMemcpyDeviceToHost, st));
+  if (mem == MSFL_MEM_HOST || info) HIPCHK(h, hipStreamSynchronize(st));
+  return MSFL_OK;
+}
+
+msfl_status msfl_match_scan2map_batch(msfl_handle* h, int n_scans, const msfl_point* corner, const int* corner_off,
+                                      const msfl_point* surf, const int* surf_off, double* poses_io, int* status,
+                                      msfl_match_info* info, msfl_mem mem) {
+  msfl_status s = enter(h); if (s) return s;
+  return match_batch_impl(h, n_scans, corner, corner_off, surf, surf_off, poses_io, status, info, mem, nullptr);
+}
+
+msfl_status msfl_match_scan2map(msfl_handle* h, const msfl_point* corner, int n_corner, const msfl_point* surf,
+                                int n_surf, double pose_io[7], msfl_match_info* info, msfl_mem mem) {
+  msfl_status s = enter(h); if (s) return s;
+  if (n_corner < 0 || n_surf < 0 || !pose_io) return fail(h, MSFL_BAD_ARG, "msfl_match_scan2map: bad argument");
+  const int co[2] = {0, n_corner}, so[2] = {0, n_surf};
+  int st = 0;
+  int* stp = (mem == MSFL_MEM_HOST) ? &st : nullptr;
+  s = match_batch_impl(h, 1, corner, co, surf, so, pose_io, stp, info, mem, nullptr);
+  if (s) return s;
+  return (msfl_status)st;
+}
+
+msfl_status msfl_match_scan2map_deskew(msfl_handle* h, const msfl_point* corner, int n_corner, const msfl_point* surf,
+                                       int n_surf, const msfl_deskew* deskew, double pose_io[7], msfl_match_info* info) {
+  msfl_status s = enter(h); if (s) return s;
+  if (n_corner < 0 || n_surf < 0 || !pose_io || !deskew) return fail(h, MSFL_BAD_ARG, "msfl_match_scan2map_deskew: bad argument");
+  const int co[2] = {0, n_corner}, so[2] = {0, n_surf};
+  int st = 0;
+  s = match_batch_impl(h, 1, corner, co, surf, so, pose_io, &st, info, MSFL_MEM_HOST, deskew);
+  if (s) return s;
+  return (msfl_status)st;
+}
+
+static msfl_status stage_single(msfl_handle* h, const msfl_point* corner, int n_corner, const msfl_point* surf, int n_surf,
+                                const double* pose, BatchView& bv) {
+  hipStream_t st = h->stream;
+  HIPCHK(h, h->in_corner.reserve(std::max<size_t>(1, (size_t)n_corner) * sizeof(float4)));
+  HIPCHK(h, h->in_surf.reserve(std::max<size_t>(1, (size_t)n_surf) * sizeof(float4)));
+  HIPCHK(h, h->poses.reserve(7 * sizeof(double)));
+  HIPCHK(h, h->status.reserve(sizeof(int)));
+  HIPCHK(h, h->in_off.reserve(6 * sizeof(int)));
+  HIPCHK(h, h->records.reserve(std::max<size_t>(1, (size_t)(n_corner + n_surf)) * 6 * sizeof(double)));
+  if (n_corner) HIPCHK(h, hipMemcpyAsync(h->in_corner.p, corner, (size_t)n_corner * sizeof(float4), hipMemcpyHostToDevice, st));
+  if (n_surf) HIPCHK(h, hipMemcpyAsync(h->in_surf.p, surf, (size_t)n_surf * sizeof(float4), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(h->poses.p, pose, 7 * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemsetAsync(h->status.p, 0, sizeof(int), st));
+  const int offs[6] = {0, n_corner, 0, n_surf, 0, n_corner + n_surf};
+  HIPCHK(h, hipMemcpyAsync(h->in_off.p, offs, sizeof(offs), hipMemcpyHostToDevice, st));
+  bv.corner = h->in_corner.as<float4>(); bv.corner_off = h->in_off.as<int>();
+  bv.surf = h->in_surf.as<float4>(); bv.surf_off = h->in_off.as<int>() + 2;
+  bv.rec_off = h->in_off.as<int>() + 4;
+  bv.n_scans = 1; bv.n_records = n_corner + n_surf;
+  return MSFL_OK;
+}
+
+msfl_status msfl_associate_scan2map(msfl_handle* h, const msfl_point* corner, int n_corner, const msfl_point* surf,
+                                    int n_surf, const double pose[7], double* records_out) {
+  msfl_status s = enter(h); if (s) return s;
+  if (n_corner < 0 || n_surf < 0 || !pose || (n_corner + n_surf > 0 && !records_out) || (n_corner && !corner) || (n_surf && !surf))
+    return fail(h, MSFL_BAD_ARG, "msfl_associate_scan2map: bad argument");
+  s = check_map(h); if (s) return s;
+  const int n = n_corner + n_surf;
+  if (n == 0) return MSFL_OK;
+  BatchView bv;
+  s = stage_single(h, corner, n_corner, surf, n_surf, pose, bv); if (s) return s;
+  DeskewView dv{};
+  {
+    ScopedTimer timer(h, T_ASSOC);
+    hipLaunchKernelGGL(assoc_scan2map_kernel<false>, dim3(div_up(n, 256)), dim3(256), 0, h->stream, bv,
+                       (const double*)h->poses.as<double>(), (const int*)h->status.as<int>(),
+                       h->map_c.g, h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                       h->map_s.g, h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                       h->prm.map_knn_max_sq_dist, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
+                       h->records.as<double>());
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(records_out, h->records.p, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MSFL_OK;
+}
+
+msfl_status msfl_solve_records(msfl_handle* h, const msfl_point* corner, int n_corner, const msfl_point* surf, int n_surf,
+                               const double* records, double pose_io[7], msfl_match_info* info) {
+  msfl_status s = enter(h); if (s) return s;
+  if (n_corner < 0 || n_surf < 0 || !pose_io || (n_corner + n_surf > 0 && !records) || (n_corner && !corner) || (n_surf && !surf))
+    return fail(h, MSFL_BAD_ARG, "msfl_solve_records: bad argument");
+  const int n = n_corner + n_surf;
+  BatchView bv;
+  s = stage_single(h, corner, n_corner, surf, n_surf, pose_io, bv); if (s) return s;
+  if (n) HIPCHK(h, hipMemcpyAsync(h->records.p, records, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  DevMatchInfo* d_info = nullptr;
+  if (info) {
+    HIPCHK(h, h->info.reserve(sizeof(DevMatchInfo)));
+    HIPCHK(h, hipMemsetAsync(h->info.p, 0, sizeof(DevMatchInfo), h->stream));
+    d_info = h->info.as<DevMatchInfo>();
+  }
+  {
+    ScopedTimer timer(h, T_SOLVE);
+    hipLaunchKernelGGL(lm_solve_kernel<256>, dim3(1), dim3(256), 0, h->stream, bv, (const double*)nullptr,
+                       (const double*)h->records.as<double>(), h->poses.as<double>(), h->status.as<int>(), d_info, 0,
+                       solver_params(h->prm, 0));
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(pose_io, h->poses.p, 7 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (info) HIPCHK(h, hipMemcpyAsync(info, d_info, sizeof(DevMatchInfo), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MSFL_OK;
+}
+
+}  // extern "C"
+
+#include "msfl_api_stage_ab.inc"

@@ -1,0 +1,692 @@
+// msfl_kernels.cuh — HIP kernels of the scan-to-map registration path (gfx950 / CDNA4).
+//
+//   K3  map grid index      replaces pcl::KdTreeFLANN::setInputCloud   mapping_scan_matcher.cc:66-73
+//   K4  assoc_scan2map      replaces the two association loops         mapping_scan_matcher.cc:109-246
+//   K5+K6 lm_solve          replaces ceres::Solve (LM, Huber)          mapping_scan_matcher.cc:250-272
+//
+// Data layout in HBM:
+//   features     float4 {x,y,z,t} per point, scans concatenated, B+1 prefix offsets
+//   map (sorted) float4 {x,y,z, bits(original index)} ordered by grid cell (x fastest)
+//   cell_start   int[n_cells+1]
+//   records      6 doubles {C, N} per feature (48 B); N == 0 marks a rejected correspondence
+//   poses        7 doubles per scan
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "msfl_math.cuh"
+
+namespace msfl {
+
+// ---------------------------------------------------------------------------------------------
+// K3: uniform-grid index.  Cell edge >= 1.001 * sqrt(max_sq_dist) so the 27-cell neighbourhood
+// of a query contains every map point whose f32 distance can pass the reference's
+// `pointSearchSqDis[4] < 1.0` gate: exact-kNN-equivalent on every ACCEPTED query.
+// ---------------------------------------------------------------------------------------------
+struct GridDesc {
+  float ox, oy, oz;   // origin = bbox min
+  float inv_cell;
+  int dx, dy, dz;
+  int n_pts;          // finite points indexed
+  int n_cells;
+};
+
+// order-preserving float <-> int encoding for atomicMin/Max
+__device__ __forceinline__ int float_to_ordered(float f) {
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__host__ __device__ __forceinline__ float ordered_to_float(int i) {
+  const int j = i >= 0 ? i : i ^ 0x7fffffff;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __int_as_float(j);
+#else
+  float f; __builtin_memcpy(&f, &j, 4); return f;
+#endif
+}
+
+// bbox[0..2] = min (ordered ints), bbox[3..5] = max; pre-initialised to INT_MAX / INT_MIN
+__global__ void __launch_bounds__(256) grid_bbox_kernel(const float4* __restrict__ pts, int n, int* __restrict__ bbox) {
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p = pts[i];
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+      mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+      mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      if (mn[a] <= mx[a]) {
+        atomicMin(&bbox[a], float_to_ordered(mn[a]));
+        atomicMax(&bbox[3 + a], float_to_ordered(mx[a]));
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ int grid_coord(float v, float o, float inv, int dim) {
+  // clamp in float first: far-away queries must not overflow the int conversion
+  float u = floorf((v - o) * inv);
+  u = fminf(fmaxf(u, -2.0f), (float)dim + 1.0f);
+  return (int)u;
+}
+
+__global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restrict__ pts, int n, GridDesc g,
+                                                          int* __restrict__ cell_of, int* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  int c = -1;
+  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+    int cx = grid_coord(p.x, g.ox, g.inv_cell, g.dx); cx = min(max(cx, 0), g.dx - 1);
+    int cy = grid_coord(p.y, g.oy, g.inv_cell, g.dy); cy = min(max(cy, 0), g.dy - 1);
+    int cz = grid_coord(p.z, g.oz, g.inv_cell, g.dz); cz = min(max(cz, 0), g.dz - 1);
+    c = (cz * g.dy + cy) * g.dx + cx;
+    atomicAdd(&count[c], 1);
+  }
+  cell_of[i] = c;
+}
+
+// cursor[] holds the per-cell counts on entry and is consumed; the order inside a cell is
+// arbitrary, which is harmless because the kNN selection uses the total order (d2, original index).
+__global__ void __launch_bounds__(256) grid_scatter_kernel(const float4* __restrict__ pts, int n,
+                                                            const int* __restrict__ cell_of,
+                                                            const int* __restrict__ cell_start, int* __restrict__ cursor,
+                                                            float4* __restrict__ sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = cell_of[i];
+  if (c < 0) return;
+  const int k = atomicSub(&cursor[c], 1) - 1;
+  float4 p = pts[i];
+  p.w = __int_as_float(i);
+  sorted[cell_start[c] + k] = p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: association = transform + exact 5-NN + line / plane fit -> {C, N} record
+// ---------------------------------------------------------------------------------------------
+
+struct Top5 {
+  float d0, d1, d2, d3, d4;
+  int i0, i1, i2, i3, i4;     // original map index (tie-break key)
+  int p0, p1, p2, p3, p4;     // position in the sorted map array
+};
+
+__device__ __forceinline__ bool knn_less(float da, int ia, float db, int ib) {
+  return da < db || (da == db && ia < ib);
+}
+
+#define MSFL_CSWAP(DA, IA, PA, DB, IB, PB)                        \
+  if (knn_less(DB, IB, DA, IA)) {                                 \
+    const float td = DA; DA = DB; DB = td;                        \
+    const int ti = IA; IA = IB; IB = ti;                          \
+    const int tp = PA; PA = PB; PB = tp;                          \
+  }
+
+__device__ __forceinline__ void top5_insert(Top5& t, float d, int idx, int pos) {
+  if (!knn_less(d, idx, t.d4, t.i4)) return;
+  t.d4 = d; t.i4 = idx; t.p4 = pos;
+  MSFL_CSWAP(t.d3, t.i3, t.p3, t.d4, t.i4, t.p4)
+  MSFL_CSWAP(t.d2, t.i2, t.p2, t.d3, t.i3, t.p3)
+  MSFL_CSWAP(t.d1, t.i1, t.p1, t.d2, t.i2, t.p2)
+  MSFL_CSWAP(t.d0, t.i0, t.p0, t.d1, t.i1, t.p1)
+}
+
+// flann::L2_Simple<float>: ((dx*dx) + dy*dy) + dz*dz, every operation rounded to f32
+__device__ __forceinline__ float l2_simple(float4 a, float3 q) {
+  const float dx = a.x - q.x, dy = a.y - q.y, dz = a.z - q.z;
+  float r = dx * dx;
+  r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+
+__device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __restrict__ sorted,
+                                          const int* __restrict__ cell_start, float3 q, Top5& t) {
+  t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = INFINITY;
+  t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0x7fffffff;
+  t.p0 = t.p1 = t.p2 = t.p3 = t.p4 = -1;
+  const int cx = grid_coord(q.x, g.ox, g.inv_cell, g.dx);
+  const int cy = grid_coord(q.y, g.oy, g.inv_cell, g.dy);
+  const int cz = grid_coord(q.z, g.oz, g.inv_cell, g.dz);
+  const int xs = max(cx - 1, 0), xe = min(cx + 1, g.dx - 1);
+  if (xs > xe) return;
+  for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); z++) {
+    for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); y++) {
+      const int row = (z * g.dy + y) * g.dx;
+      // the three x-adjacent cells are contiguous in the sorted array: one range per (y, z)
+      const int s = cell_start[row + xs], e = cell_start[row + xe + 1];
+      for (int k = s; k < e; k++) {
+        const float4 m = sorted[k];
+        top5_insert(t, l2_simple(m, q), __float_as_int(m.w), k);
+      }
+    }
+  }
+}
+
+struct FitOut { d3 C, N; bool ok; };
+
+// mapping_scan_matcher.cc:130-151
+__device__ __forceinline__ FitOut edge_fit(const float4 (&nb)[5], double ratio) {
+  FitOut o; o.ok = false; o.C = mk3(0, 0, 0); o.N = mk3(0, 0, 0);
+  d3 m[5];
+  d3 c = mk3(0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 5; j++) { m[j] = mk3((double)nb[j].x, (double)nb[j].y, (double)nb[j].z); c = c + m[j]; }
+  c = mk3(c.x / 5.0, c.y / 5.0, c.z / 5.0);
+  sym3 S = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const d3 d = m[j] - c;
+    S.a00 += d.x * d.x; S.a01 += d.x * d.y; S.a02 += d.x * d.z;
+    S.a11 += d.y * d.y; S.a12 += d.y * d.z; S.a22 += d.z * d.z;
+  }
+  double e1, e2; d3 dir;
+  sym_eigen3_top(S, e1, e2, dir);
+  if (!(e2 > ratio * e1)) return o;
+  const d3 pa = mk3(0.1 * dir.x + c.x, 0.1 * dir.y + c.y, 0.1 * dir.z + c.z);
+  const d3 pb = mk3(-0.1 * dir.x + c.x, -0.1 * dir.y + c.y, -0.1 * dir.z + c.z);
+  o.N = normalized(pa - pb);
+  o.C = pa;
+  o.ok = true;
+  return o;
+}
+
+// mapping_scan_matcher.cc:199-222
+__device__ __forceinline__ FitOut plane_fit(const float4 (&nb)[5], double tol) {
+  FitOut o; o.ok = false; o.C = mk3(0, 0, 0); o.N = mk3(0, 0, 0);
+  double A[5][3], b[5];
+  d3 c = mk3(0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    A[j][0] = (double)nb[j].x; A[j][1] = (double)nb[j].y; A[j][2] = (double)nb[j].z;
+    b[j] = -1.0;
+    c = c + mk3(A[j][0], A[j][1], A[j][2]);
+  }
+  c = mk3(c.x / 5.0, c.y / 5.0, c.z / 5.0);
+  const d3 n = normalized(lstsq5x3(A, b));   // note: lstsq5x3 overwrites A, b
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const double d = n.x * ((double)nb[j].x - c.x) + n.y * ((double)nb[j].y - c.y) + n.z * ((double)nb[j].z - c.z);
+    if (fabs(d) > tol) ok = false;
+  }
+  if (!ok) return o;
+  o.C = c; o.N = n; o.ok = true;
+  return o;
+}
+
+struct BatchView {
+  const float4* corner; const int* corner_off;
+  const float4* surf;   const int* surf_off;
+  const int* rec_off;       // rec_off[b] = corner_off[b] + surf_off[b]
+  int n_scans;
+  int n_records;            // rec_off[n_scans]
+};
+
+// scan owning global record index g (upper bound - 1 over rec_off)
+__device__ __forceinline__ int find_scan(const int* __restrict__ rec_off, int n_scans, int g) {
+  int lo = 0, hi = n_scans;      // invariant: rec_off[lo] <= g < rec_off[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (rec_off[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+struct DeskewView {
+  // all null for the plain (LiDAR-only) branch
+  const double* corner_dq; const double* corner_dp;
+  const double* surf_dq;   const double* surf_dp;
+  double V[3], G[3];
+  double* pprime;           // out: n_records x 3, p' = dq*p + dp
+};
+
+template <bool DESKEW>
+__global__ void __launch_bounds__(256)
+assoc_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
+                      GridDesc gc, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
+                      GridDesc gs, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
+                      float max_sq_dist, double line_ratio, double plane_tol,
+                      DeskewView dv, double* __restrict__ rec) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= bv.n_records) return;
+  const int b = find_scan(bv.rec_off, bv.n_scans, g);
+  double* out = rec + 6 * (size_t)g;
+  if (status[b] != 0) {   // scan already failed: leave an empty record
+#pragma unroll
+    for (int k = 0; k < 6; k++) out[k] = 0.0;
+    return;
+  }
+  const int local = g - bv.rec_off[b];
+  const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
+  const bool is_edge = local < nc;
+  const int fi = is_edge ? bv.corner_off[b] + local : bv.surf_off[b] + (local - nc);
+  const float4 f = is_edge ? bv.corner[fi] : bv.surf[fi];
+  const pose7 T = load_pose(poses + 7 * b);
+  float3 q;
+  d3 shift = mk3(0, 0, 0);
+  if (DESKEW) {
+    // mapping_scan_matcher.cc:120 / :190: pose * Rigid3d{q^-1 (Vi dt - G dt^2/2) + dp, dq}
+    const double* dqp = is_edge ? dv.corner_dq + 4 * (size_t)fi : dv.surf_dq + 4 * (size_t)fi;
+    const double* dpp = is_edge ? dv.corner_dp + 3 * (size_t)fi : dv.surf_dp + 3 * (size_t)fi;
+    quat dq; dq.x = dqp[0]; dq.y = dqp[1]; dq.z = dqp[2]; dq.w = dqp[3];
+    const d3 dp = mk3(dpp[0], dpp[1], dpp[2]);
+    const double dt = (double)f.w;
+    shift = mk3(dv.V[0] * dt - 0.5 * dv.G[0] * dt * dt, dv.V[1] * dt - 0.5 * dv.G[1] * dt * dt,
+                dv.V[2] * dt - 0.5 * dv.G[2] * dt * dt);
+    quat qc; qc.x = -T.q.x; qc.y = -T.q.y; qc.z = -T.q.z; qc.w = T.q.w;
+    pose7 full;
+    full.t = quat_rotate(T.q, quat_rotate(qc, shift) + dp) + T.t;       // Rigid3d operator*
+    full.q = quat_normalized(quat_mul(T.q, dq));
+    q = transform_point_f32(full, f.x, f.y, f.z);
+    const d3 pp = quat_rotate(dq, mk3((double)f.x, (double)f.y, (double)f.z)) + dp;
+    dv.pprime[3 * (size_t)g + 0] = pp.x; dv.pprime[3 * (size_t)g + 1] = pp.y; dv.pprime[3 * (size_t)g + 2] = pp.z;
+  } else {
+    q = transform_point_f32(T, f.x, f.y, f.z);                          // :123 / :193
+  }
+  Top5 t;
+  if (is_edge) knn5_grid(gc, map_c, cs_c, q, t); else knn5_grid(gs, map_s, cs_s, q, t);
+  FitOut fo; fo.ok = false; fo.C = mk3(0, 0, 0); fo.N = mk3(0, 0, 0);
+  if (t.p4 >= 0 && (double)t.d4 < (double)max_sq_dist) {                // :128 / :198
+    const float4* mp = is_edge ? map_c : map_s;
+    const float4 nb[5] = {mp[t.p0], mp[t.p1], mp[t.p2], mp[t.p3], mp[t.p4]};
+    fo = is_edge ? edge_fit(nb, line_ratio) : plane_fit(nb, plane_tol);
+    if (DESKEW && fo.ok) fo.C = fo.C - shift;   // C' = C - (Vi dt - G dt^2/2), velocity block constant (.cc:94)
+  }
+  out[0] = fo.C.x; out[1] = fo.C.y; out[2] = fo.C.z;
+  out[3] = fo.N.x; out[4] = fo.N.y; out[5] = fo.N.z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5 + K6: persistent per-scan trust-region LM with Huber loss (Ceres semantics)
+// ---------------------------------------------------------------------------------------------
+
+struct SolverParams {
+  int    max_iterations;
+  double huber;
+  double radius0, radius_max, radius_min;
+  double min_relative_decrease, min_diag, max_diag;
+  double ftol, gtol, ptol;
+  int    max_invalid;
+  int    min_correspondences;   // 0 for the mapping matcher, 10 for odometry (.cc:262)
+};
+
+struct DevMatchInfo {   // mirrors msfl_match_info
+  int status;
+  int n_edge[2], n_plane[2];
+  int lm_iterations[2], lm_successful[2];
+  double initial_cost[2], final_cost[2];
+};
+
+constexpr int kAcc = 28;   // cost + g[6] + H upper[21]
+
+// row of the (robustified) Jacobian: a = d r/d t (3), rotation part b = -M^T a, residual ra
+__device__ __forceinline__ void acc_row(double (&acc)[kAcc], const mat3& M, d3 a, double ra, double sc) {
+  const double b0 = -(M.m[0] * a.x + M.m[3] * a.y + M.m[6] * a.z);
+  const double b1 = -(M.m[1] * a.x + M.m[4] * a.y + M.m[7] * a.z);
+  const double b2 = -(M.m[2] * a.x + M.m[5] * a.y + M.m[8] * a.z);
+  const double j[6] = {sc * a.x, sc * a.y, sc * a.z, sc * b0, sc * b1, sc * b2};
+  const double r = sc * ra;
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc[1 + k] += j[k] * r;
+  int n = 7;
+#pragma unroll
+  for (int p = 0; p < 6; p++)
+#pragma unroll
+    for (int q = p; q < 6; q++) acc[n++] += j[p] * j[q];
+}
+
+__device__ __forceinline__ void huber_rho(double a, double s, double& rho0, double& rho1) {
+  const double b = a * a;
+  if (s > b) {
+    const double r = sqrt(s);
+    rho0 = 2.0 * a * r - b;
+    rho1 = fmax(2.2250738585072014e-308, a / r);
+  } else {
+    rho0 = s; rho1 = 1.0;
+  }
+}
+
+// One evaluation pass of a scan's records at pose T: cost, g = J^T r, H = J^T J (robustified,
+// tangent space).  lidar_factor.cc:7-44 + Ceres HuberLoss/Corrector.
+template <int BLOCK>
+__device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
+                                              const float4* __restrict__ corner, int nc,
+                                              const float4* __restrict__ surf, int ns,
+                                              const double* __restrict__ pprime,   // may be null
+                                              const double* __restrict__ rec,      // this scan's records
+                                              double (&acc)[kAcc], int& n_edge, int& n_plane) {
+#pragma unroll
+  for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
+  n_edge = 0; n_plane = 0;
+  const mat3 R = quat_to_matrix(T.q);
+  const int n = nc + ns;
+  for (int i = threadIdx.x; i < n; i += BLOCK) {
+    const double* r6 = rec + 6 * (size_t)i;
+    const d3 C = mk3(r6[0], r6[1], r6[2]);
+    const d3 N = mk3(r6[3], r6[4], r6[5]);
+    if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) continue;      // rejected correspondence
+    const bool is_edge = i < nc;
+    d3 p;
+    if (pprime) {
+      p = mk3(pprime[3 * (size_t)i], pprime[3 * (size_t)i + 1], pprime[3 * (size_t)i + 2]);
+    } else {
+      const float4 f = is_edge ? corner[i] : surf[i - nc];
+      p = mk3((double)f.x, (double)f.y, (double)f.z);          // curr_point: untransformed (:146, :221)
+    }
+    const d3 d = quat_rotate(T.q, p) + T.t - C;
+    // M = R * skew(p)
+    mat3 M;
+    M.m[0] = R.m[1] * p.z - R.m[2] * p.y; M.m[1] = -R.m[0] * p.z + R.m[2] * p.x; M.m[2] = R.m[0] * p.y - R.m[1] * p.x;
+    M.m[3] = R.m[4] * p.z - R.m[5] * p.y; M.m[4] = -R.m[3] * p.z + R.m[5] * p.x; M.m[5] = R.m[3] * p.y - R.m[4] * p.x;
+    M.m[6] = R.m[7] * p.z - R.m[8] * p.y; M.m[7] = -R.m[6] * p.z + R.m[8] * p.x; M.m[8] = R.m[6] * p.y - R.m[7] * p.x;
+    if (is_edge) {
+      n_edge++;
+      const d3 r = cross(N, d);                                // lidar_factor.cc:12
+      const double s = r.x * r.x + r.y * r.y + r.z * r.z;
+      double rho0, rho1; huber_rho(huber, s, rho0, rho1);
+      acc[0] += 0.5 * rho0;
+      const double sc = sqrt(rho1);
+      acc_row(acc, M, mk3(0.0, -N.z, N.y), r.x, sc);           // rows of skew(N), :18-19
+      acc_row(acc, M, mk3(N.z, 0.0, -N.x), r.y, sc);
+      acc_row(acc, M, mk3(-N.y, N.x, 0.0), r.z, sc);
+    } else {
+      n_plane++;
+      const double r = dot(N, d);                              // lidar_factor.cc:32
+      double rho0, rho1; huber_rho(huber, r * r, rho0, rho1);
+      acc[0] += 0.5 * rho0;
+      acc_row(acc, M, N, r, sqrt(rho1));                       // :38-39
+    }
+  }
+}
+
+template <int BLOCK>
+struct LmShared {
+  double part[BLOCK / 64][kAcc];
+  double red[kAcc];          // reduced {cost, g, H} of the last pass
+  int    cnt_part[BLOCK / 64][2];
+  int    cnt[2];
+  double x[7];               // current iterate
+  double cand[7];            // candidate
+  int    go;                 // 1: evaluate candidate, 0: finished
+};
+
+// deterministic block reduction: butterfly inside the wave, fixed order across waves
+template <int BLOCK>
+__device__ __forceinline__ void block_reduce(LmShared<BLOCK>& sh, double (&acc)[kAcc], int n_edge, int n_plane) {
+#pragma unroll
+  for (int k = 0; k < kAcc; k++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { n_edge += __shfl_xor(n_edge, o); n_plane += __shfl_xor(n_plane, o); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < kAcc; k++) sh.part[wave][k] = acc[k];
+    sh.cnt_part[wave][0] = n_edge; sh.cnt_part[wave][1] = n_plane;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAcc) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) s += sh.part[w][threadIdx.x];
+    sh.red[threadIdx.x] = s;
+  } else if (threadIdx.x < kAcc + 2) {
+    int s = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) s += sh.cnt_part[w][threadIdx.x - kAcc];
+    sh.cnt[threadIdx.x - kAcc] = s;
+  }
+  __syncthreads();
+}
+
+// 6x6 SPD solve by Cholesky, fully unrolled; A symmetric (full storage), returns false if not PD
+__device__ __forceinline__ bool chol_solve6(const double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
+  double L[6][6];
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      double s = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+      if (i == j) {
+        if (!(s > 0.0)) ok = false;
+        L[i][i] = sqrt(s);
+      } else {
+        L[i][j] = s / L[j][j];
+      }
+    }
+  }
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[i][k] * y[k];
+    y[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) s -= L[k][i] * x[k];
+    x[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) if (!isfinite(x[i])) ok = false;
+  return ok;
+}
+
+__device__ __forceinline__ double gradient_max_norm(const pose7& x, const double (&g)[6]) {
+  const pose7 xp = pose_plus(x, mk3(-g[0], -g[1], -g[2]), mk3(-g[3], -g[4], -g[5]));
+  double m = fabs(x.t.x - xp.t.x);
+  m = fmax(m, fabs(x.t.y - xp.t.y)); m = fmax(m, fabs(x.t.z - xp.t.z));
+  m = fmax(m, fabs(x.q.x - xp.q.x)); m = fmax(m, fabs(x.q.y - xp.q.y));
+  m = fmax(m, fabs(x.q.z - xp.q.z)); m = fmax(m, fabs(x.q.w - xp.q.w));
+  return m;
+}
+__device__ __forceinline__ double pose_norm(const pose7& x) {
+  return sqrt(x.t.x * x.t.x + x.t.y * x.t.y + x.t.z * x.t.z + x.q.x * x.q.x + x.q.y * x.q.y + x.q.z * x.q.z + x.q.w * x.q.w);
+}
+
+// unpack the reduced accumulator into full H (6x6), g
+__device__ __forceinline__ void unpack_system(const double* red, double (&H)[6][6], double (&g)[6]) {
+#pragma unroll
+  for (int k = 0; k < 6; k++) g[k] = red[1 + k];
+  int n = 7;
+#pragma unroll
+  for (int p = 0; p < 6; p++)
+#pragma unroll
+    for (int q = p; q < 6; q++) { H[p][q] = red[n]; H[q][p] = red[n]; n++; }
+}
+
+// One workgroup per scan, persistent over all trust-region iterations of one ceres::Solve.
+// Thread 0 runs the (serial, tiny) trust-region logic between evaluation passes; every pass
+// evaluates cost AND the normal equations at the candidate, so an accepted step needs no second
+// pass (Ceres re-evaluates; the values are identical).
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const double* __restrict__ rec_all,
+                double* __restrict__ poses, int* __restrict__ status, DevMatchInfo* __restrict__ info,
+                int outer_it, SolverParams prm) {
+  __shared__ LmShared<BLOCK> sh;
+  const int b = blockIdx.x;
+  if (status[b] != 0) return;
+  const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
+  const int ns = bv.surf_off[b + 1] - bv.surf_off[b];
+  const float4* corner = bv.corner + bv.corner_off[b];
+  const float4* surf = bv.surf + bv.surf_off[b];
+  const size_t r0 = (size_t)bv.rec_off[b];
+  const double* rec = rec_all + 6 * r0;
+  const double* pprime = pprime_all ? pprime_all + 3 * r0 : nullptr;
+  double* pose_g = poses + 7 * (size_t)b;
+
+  double acc[kAcc];
+  int ne, np;
+  pose7 T = load_pose(pose_g);
+  evaluate_pass<BLOCK>(T, prm.huber, corner, nc, surf, ns, pprime, rec, acc, ne, np);
+  block_reduce<BLOCK>(sh, acc, ne, np);
+
+  // trust-region state, owned by thread 0 (kept in registers of lane 0 only)
+  double H[6][6], g[6], scale[6], diagonal[6];
+  double cost = 0, gmax = 0, x_norm = 0, radius = prm.radius0, decrease_factor = 2.0, model_cost_change = 0;
+  pose7 x = T, cand = T;
+  int iteration = 0, invalid = 0, successful = 0;
+  bool reuse_diagonal = false, step_ok = true;
+
+  if (threadIdx.x == 0) {
+    const int n_edge = sh.cnt[0], n_plane = sh.cnt[1];
+    int go = 1;
+    if (info) { info[b].n_edge[outer_it] = n_edge; info[b].n_plane[outer_it] = n_plane; }
+    if (n_edge + n_plane < prm.min_correspondences) {
+      status[b] = 1;                       // MSFL_TOO_FEW_CORRESPONDENCES (odometry_scan_matcher.cc:262-267)
+      if (info) info[b].status = 1;
+      go = 0;
+    } else if (n_edge + n_plane == 0) {
+      go = 0;                              // Ceres: empty problem, parameters untouched
+    } else {
+      unpack_system(sh.red, H, g);
+      cost = sh.red[0];
+      if (info) info[b].initial_cost[outer_it] = cost;
+#pragma unroll
+      for (int i = 0; i < 6; i++) scale[i] = 1.0 / (1.0 + sqrt(H[i][i]));   // jacobi_scaling, iteration 0
+      gmax = gradient_max_norm(x, g);
+      x_norm = pose_norm(x);
+    }
+    sh.go = go;
+  }
+  __syncthreads();
+  if (!sh.go) {
+    if (threadIdx.x == 0 && info) { info[b].lm_iterations[outer_it] = 0; info[b].lm_successful[outer_it] = 0; info[b].final_cost[outer_it] = cost; }
+    return;
+  }
+
+  for (;;) {
+    if (threadIdx.x == 0) {
+      int go = 0;
+      // FinalizeIterationAndCheckIfMinimizerCanContinue + ComputeTrustRegionStep; loops here
+      // over invalid steps (they need no evaluation pass)
+      for (;;) {
+        if (iteration >= prm.max_iterations) break;
+        if (step_ok && gmax <= prm.gtol) break;
+        if (radius < prm.radius_min) break;
+        iteration++;
+        double Hs[6][6], gs[6], A[6][6], y[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          gs[i] = g[i] * scale[i];
+#pragma unroll
+          for (int j = 0; j < 6; j++) Hs[i][j] = H[i][j] * scale[i] * scale[j];
+        }
+        if (!reuse_diagonal) {
+#pragma unroll
+          for (int i = 0; i < 6; i++) diagonal[i] = fmin(fmax(Hs[i][i], prm.min_diag), prm.max_diag);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+          for (int j = 0; j < 6; j++) A[i][j] = Hs[i][j];
+          const double lm = sqrt(diagonal[i] / radius);
+          A[i][i] += lm * lm;
+        }
+        const bool ok = chol_solve6(A, gs, y);
+        reuse_diagonal = true;
+        double step[6];
+        model_cost_change = 0.0;
+        if (ok) {
+          double gts = 0.0, shs = 0.0;
+#pragma unroll
+          for (int i = 0; i < 6; i++) step[i] = -y[i];
+#pragma unroll
+          for (int i = 0; i < 6; i++) {
+            gts += gs[i] * step[i];
+#pragma unroll
+            for (int j = 0; j < 6; j++) shs += step[i] * Hs[i][j] * step[j];
+          }
+          model_cost_change = -gts - 0.5 * shs;
+        }
+        if (!ok || !(model_cost_change > 0.0)) {          // HandleInvalidStep
+          if (++invalid >= prm.max_invalid) break;
+          radius *= 0.5;
+          step_ok = false;
+          continue;
+        }
+        invalid = 0;
+        cand = pose_plus(x, mk3(step[0] * scale[0], step[1] * scale[1], step[2] * scale[2]),
+                         mk3(step[3] * scale[3], step[4] * scale[4], step[5] * scale[5]));
+        // ParameterToleranceReached (needs no evaluation)
+        const double dx0 = x.t.x - cand.t.x, dx1 = x.t.y - cand.t.y, dx2 = x.t.z - cand.t.z;
+        const double dx3 = x.q.x - cand.q.x, dx4 = x.q.y - cand.q.y, dx5 = x.q.z - cand.q.z, dx6 = x.q.w - cand.q.w;
+        const double sn = sqrt(dx0 * dx0 + dx1 * dx1 + dx2 * dx2 + dx3 * dx3 + dx4 * dx4 + dx5 * dx5 + dx6 * dx6);
+        if (sn <= prm.ptol * (x_norm + prm.ptol)) break;
+        go = 1;
+        break;
+      }
+      if (go) store_pose(sh.cand, cand);
+      sh.go = go;
+    }
+    __syncthreads();
+    if (!sh.go) break;
+    T = load_pose(sh.cand);
+    evaluate_pass<BLOCK>(T, prm.huber, corner, nc, surf, ns, pprime, rec, acc, ne, np);
+    block_reduce<BLOCK>(sh, acc, ne, np);
+    if (threadIdx.x == 0) {
+      const double cand_cost = sh.red[0];
+      const double cost_change = cost - cand_cost;
+      bool stop = false;
+      if (fabs(cost_change) <= prm.ftol * cost) {           // FunctionToleranceReached
+        stop = true;
+      } else {
+        const double rel = cost_change / model_cost_change;
+        if (rel > prm.min_relative_decrease) {              // HandleSuccessfulStep
+          x = cand;
+          x_norm = pose_norm(x);
+          unpack_system(sh.red, H, g);
+          cost = cand_cost;
+          gmax = gradient_max_norm(x, g);
+          const double t = 2.0 * rel - 1.0;
+          radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+          radius = fmin(radius, prm.radius_max);
+          decrease_factor = 2.0;
+          reuse_diagonal = false;
+          step_ok = true;
+          successful++;
+        } else {                                            // HandleUnsuccessfulStep
+          radius = radius / decrease_factor;
+          decrease_factor *= 2.0;
+          reuse_diagonal = true;
+          step_ok = false;
+        }
+      }
+      sh.go = stop ? 0 : 1;
+    }
+    __syncthreads();
+    if (!sh.go) break;
+  }
+  if (threadIdx.x == 0) {
+    store_pose(pose_g, x);
+    if (info) {
+      info[b].lm_iterations[outer_it] = iteration;
+      info[b].lm_successful[outer_it] = successful;
+      info[b].final_cost[outer_it] = cost;
+    }
+  }
+}
+
+}  // namespace msfl

@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure), built on demand from oracle/msfl_oracle.c."""
+    from oracle import oracle as orc
+    orc.build()
+    orc.lib()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """A handle on cuda:0.  Fails loudly when the HIP extension or the GPU is missing."""
+    from msf_loam_amd import capi
+    h = capi.Handle(0)
+    yield h
+    h.close()
