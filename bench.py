@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — scan-to-map registrations/s on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch: (re)index the resident 200k-point local map
+and register B = 1024 synthetic VLP-16 scans against it (2 outer iterations x [exact 5-NN
+association + line/plane fit -> Ceres-semantics LM(<=6)+Huber(0.1)]), inputs already resident in
+HBM.  With N > 1 every rank registers its own B scans (weak scaling) against a replicated map and
+the poses are gathered with one RCCL all_gather per step.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def build_inputs(B, map_points, seed_offset, extractor=None):
+    """Synthetic world/map (shared by all ranks) + this rank's B scans -> feature clouds."""
+    from msf_loam_amd import synth
+    world = synth.World(ground_half=synth.ground_half_for_target(map_points))
+    map_corner, map_surf = synth.make_map(world)
+    poses = synth.random_poses(B, synth.SEED + 2 + 7919 * seed_offset)
+    rng = np.random.default_rng(synth.SEED + 3 + 7919 * seed_offset)
+    guesses = np.stack([synth.perturb_pose(p, rng) for p in poses])
+    corner, surf, co, so = [], [], [0], [0]
+    raw = []
+    for i in range(B):
+        pts, ring, kind = synth.make_scan(world, poses[i], synth.SEED + 100 + i + 100003 * seed_offset, with_kind=True)
+        raw.append((pts, ring, kind))
+    if extractor is not None:
+        feats = extractor(raw)
+    else:
+        feats = [synth.direct_features(p, k) for p, _, k in raw]
+    for c, s in feats:
+        corner.append(c); surf.append(s)
+        co.append(co[-1] + len(c)); so.append(so[-1] + len(s))
+    return dict(map_corner=map_corner, map_surf=map_surf, truth=poses, guesses=guesses,
+                corner=np.concatenate(corner), surf=np.concatenate(surf),
+                corner_off=np.array(co, np.int32), surf_off=np.array(so, np.int32))
+
+
+def product_extractor(handle):
+    """Feature clouds through the product's own GPU path: msfl_extract_features_batch +
+    msfl_voxel_downsample (0.2 m corner / 0.4 m surf, laser_mapping.cc:264-270)."""
+    def run(raw):
+        out = []
+        chunk = 64
+        for s in range(0, len(raw), chunk):
+            part = raw[s:s + chunk]
+            pts = np.concatenate([p for p, _, _ in part])
+            ring = np.concatenate([r for _, r, _ in part])
+            off = np.cumsum([0] + [len(p) for p, _, _ in part]).astype(np.int32)
+            for f in handle.extract_features_batch(pts, ring, off):
+                c = handle.voxel_downsample(f["full"][f["less_sharp"]], 0.2)
+                sf = handle.voxel_downsample(f["full"][f["less_flat"]], 0.4)
+                out.append((c, sf))
+        return out
+    return run
+
+
+def cpu_baseline(inp, sample, threads):
+    """Oracle (CPU restatement of the reference algorithm, kd-tree rebuilt per registration like
+    mapping_scan_matcher.cc:66-73) timed on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    orc.build()
+    n = min(sample, len(inp["guesses"]))
+    co, so = inp["corner_off"][:n + 1], inp["surf_off"][:n + 1]
+    args = (inp["map_corner"], inp["map_surf"], inp["corner"][:co[-1]], co, inp["surf"][:so[-1]], so, inp["guesses"][:n])
+    n1 = max(1, min(n, 16))
+    t0 = time.perf_counter()
+    orc.match_scan2map_batch(args[0], args[1], inp["corner"][:co[n1]], co[:n1 + 1], inp["surf"][:so[n1]], so[:n1 + 1],
+                             inp["guesses"][:n1], threads=1, rebuild_tree_per_scan=True)
+    t1 = time.perf_counter()
+    single = n1 / (t1 - t0)
+    t0 = time.perf_counter()
+    poses, status = orc.match_scan2map_batch(*args, threads=threads, rebuild_tree_per_scan=True)
+    t1 = time.perf_counter()
+    return dict(value=n / (t1 - t0), single_thread_value=single, n=n, n_single=n1, poses=poses)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scans", type=int, default=1024, help="scans per GPU per step (BASELINE configs[1]: 1024)")
+    ap.add_argument("--map-points", type=int, default=200000)
+    ap.add_argument("--cpu-sample", type=int, default=128, help="scans timed on the CPU oracle (0 disables)")
+    ap.add_argument("--features", choices=["product", "direct"], default="direct",
+                    help="product: features from the GPU extraction + voxel kernels; direct: from ray-cast hit kinds")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+
+    from msf_loam_amd import capi, dist as mdist
+    h = capi.Handle(local_rank)
+    B = args.scans
+    extractor = None
+    feature_source = args.features
+    if feature_source == "product":
+        extractor = product_extractor(h)
+    t_prep = time.perf_counter()
+    inp = build_inputs(B, args.map_points, rank, extractor)
+    t_prep = time.perf_counter() - t_prep
+
+    stream = torch.cuda.current_stream(dev)
+    h.set_stream(stream.cuda_stream)
+    d_map_c = torch.from_numpy(inp["map_corner"]).to(dev)
+    d_map_s = torch.from_numpy(inp["map_surf"]).to(dev)
+    d_corner = torch.from_numpy(inp["corner"]).to(dev)
+    d_surf = torch.from_numpy(inp["surf"]).to(dev)
+    d_guess = torch.from_numpy(inp["guesses"]).to(dev)
+    d_poses = torch.empty_like(d_guess)
+    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
+    gather = mdist.PoseGather(B, dev) if world_size > 1 else None
+    n_mc, n_ms = len(inp["map_corner"]), len(inp["map_surf"])
+    co, so = inp["corner_off"], inp["surf_off"]
+
+    def step():
+        d_poses.copy_(d_guess)                                       # fresh initial guesses
+        h.set_map(d_map_c, d_map_s, n_mc, n_ms, capi.MEM_DEVICE)      # kd-tree build equivalent, per batch
+        h.match_scan2map_batch_device(B, d_corner, co, d_surf, so, d_poses, d_status)
+        if gather is not None:
+            gather.all_gather(d_poses, d_status)                     # RCCL pose gather
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    h.set_timing(True)
+    h.get_timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timing = h.get_timing(reset=True)
+    h.set_timing(False)
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    poses_gpu = d_poses.cpu().numpy()
+    status_gpu = d_status.cpu().numpy()
+
+    if rank == 0:
+        from msf_loam_amd import synth
+        total_regs = world_size * B * args.steps
+        value = total_regs / elapsed
+        F_total = int(co[-1] + so[-1])
+        n_outer = 2
+        # ALGORITHMIC bytes: per association launch = F_total*(16 query + 5*16 neighbours)
+        # + the map read once per batch, split over the n_outer launches + one pose per scan.
+        alg_bytes_assoc = F_total * 96 + (n_mc + n_ms) * 16 / n_outer + B * 56
+        assoc_ms = timing.ms_assoc / max(timing.launches_assoc, 1)
+        solve_ms = timing.ms_solve / max(timing.launches_solve, 1)
+        index_ms = timing.ms_index / max(timing.launches_index, 1)
+        achieved = alg_bytes_assoc / (assoc_ms * 1e-3) / 1e9 if assoc_ms > 0 else 0.0
+        out = {
+            "metric": "scan-to-map registrations/s", "value": value, "unit": "registrations/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 (f32 kNN distances)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch of %d VLP-16 scans (16x1800) vs %d-pt local map, "
+                                   "2 outer x [exact 5-NN + line/plane fit, LM<=6 + Huber 0.1]" % (B, n_mc + n_ms),
+                       "scans_per_gpu": B, "map_points": n_mc + n_ms, "map_corner": n_mc, "map_surf": n_ms,
+                       "features_per_scan": F_total / B, "feature_source": feature_source,
+                       "index_rebuilt_per_step": True, "parallelism": "scan-sharded x%d, map replicated" % world_size},
+            "roofline": {"bound": "hbm", "kernel": "assoc_scan2map_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes_assoc, "avg_launch_ms": assoc_ms},
+            "kernels_ms": {"assoc": assoc_ms, "solve": solve_ms, "index_build": index_ms,
+                           "launches": {"assoc": timing.launches_assoc, "solve": timing.launches_solve,
+                                        "index": timing.launches_index}},
+            "prep_s": t_prep,
+            "n_failed": int((status_gpu != 0).sum()),
+        }
+        if args.cpu_sample > 0:
+            cores = os.cpu_count() or 1
+            cb = cpu_baseline(inp, args.cpu_sample, cores)
+            dts, drs = zip(*[synth.pose_error(poses_gpu[i], cb["poses"][i]) for i in range(cb["n"])])
+            out["cpu_baseline"] = {"value": cb["value"], "unit": "registrations/s", "cores": cores, "kind": "port",
+                                   "single_thread_value": cb["single_thread_value"],
+                                   "sample": "%d of the %d scans of rank 0, oracle/msfl_oracle.c with per-registration "
+                                             "kd-tree rebuild, OpenMP over scans on %d threads (single-thread figure on %d scans)"
+                                             % (cb["n"], B, cores, cb["n_single"])}
+            out["pose_delta_vs_oracle"] = {"max_m": max(dts), "max_rad": max(drs), "n": cb["n"], "tolerance": 1e-4}
+        print(json.dumps(out))
+    if world_size > 1:
+        dist.destroy_process_group()
+    h.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -139,9 +139,12 @@ int msfl_api_version(void);
 msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out);
 void msfl_destroy(msfl_handle* h);
 
-/* Run all work of this handle on a caller-provided hipStream_t (e.g. torch's current stream);
-   NULL restores the handle's own stream. */
+/* Run all work of this handle on a caller-provided hipStream_t (e.g. torch's current stream).
+   The value is used as is: NULL means HIP's null (legacy default) stream, which is what
+   torch.cuda.current_stream().cuda_stream is unless the caller switched streams.
+   msfl_reset_stream goes back to the handle's own (non-blocking) stream. */
 msfl_status msfl_set_stream(msfl_handle* h, void* hip_stream);
+msfl_status msfl_reset_stream(msfl_handle* h);
 /* Block until everything queued by this handle has finished. */
 msfl_status msfl_synchronize(msfl_handle* h);
 

@@ -15,7 +15,7 @@ OK, TOO_FEW_CORRESPONDENCES, MAP_TOO_SMALL, BAD_ARG, HIP_ERROR, BAD_RING, NO_MAP
 MEM_HOST, MEM_DEVICE = 0, 1
 
 EXPORTED = [
-    "msfl_default_params", "msfl_api_version", "msfl_create", "msfl_destroy", "msfl_set_stream",
+    "msfl_default_params", "msfl_api_version", "msfl_create", "msfl_destroy", "msfl_set_stream", "msfl_reset_stream",
     "msfl_synchronize", "msfl_status_string", "msfl_last_error", "msfl_set_timing", "msfl_get_timing",
     "msfl_set_map", "msfl_match_scan2map", "msfl_match_scan2map_batch", "msfl_match_scan2map_deskew",
     "msfl_associate_scan2map", "msfl_solve_records",
@@ -166,6 +166,9 @@ class Handle:
     # ---- plumbing ----
     def set_stream(self, stream_ptr):
         self._check(self.lib.msfl_set_stream(self.h, C.c_void_p(stream_ptr)), "msfl_set_stream")
+
+    def reset_stream(self):
+        self._check(self.lib.msfl_reset_stream(self.h), "msfl_reset_stream")
 
     def synchronize(self):
         self._check(self.lib.msfl_synchronize(self.h), "msfl_synchronize")

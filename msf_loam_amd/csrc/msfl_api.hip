@@ -39,6 +39,42 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Ring of pinned host staging slots for small metadata uploads (offset tables, init words).
+// hipMemcpyAsync from PAGEABLE memory may read the source after the call returns when the stream
+// is busy, so metadata must live in pinned memory that stays untouched until its copy has run.
+struct PinSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+struct PinRing {
+  static constexpr int kSlots = 8;
+  PinSlot slot[kSlots];
+  int next = 0;
+  hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    PinSlot& s = slot[next];
+    next = (next + 1) % kSlots;
+    hipError_t e;
+    if (s.pending) { e = hipEventSynchronize(s.ev); if (e != hipSuccess) return e; s.pending = false; }
+    if (bytes > s.cap) {
+      if (s.p) { e = hipHostFree(s.p); if (e != hipSuccess) return e; s.p = nullptr; s.cap = 0; }
+      size_t want = (std::max<size_t>(bytes, 4096) + 4095) & ~size_t(4095);
+      e = hipHostMalloc(&s.p, want, hipHostMallocDefault); if (e != hipSuccess) return e;
+      s.cap = want;
+    }
+    if (!s.ev) { e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming); if (e != hipSuccess) return e; }
+    std::memcpy(s.p, src, bytes);
+    e = hipMemcpyAsync(dst, s.p, bytes, hipMemcpyHostToDevice, st); if (e != hipSuccess) return e;
+    e = hipEventRecord(s.ev, st); if (e != hipSuccess) return e;
+    s.pending = true;
+    return hipSuccess;
+  }
+  void release() {
+    for (auto& s : slot) {
+      if (s.pending) (void)hipEventSynchronize(s.ev);
+      if (s.ev) (void)hipEventDestroy(s.ev);
+      if (s.p) (void)hipHostFree(s.p);
+      s = PinSlot{};
+    }
+  }
+};
+
 struct MapIndex {
   GridDesc g{};
   DevBuf sorted;      // float4[n]
@@ -68,6 +104,8 @@ struct msfl_handle_s {
   DevBuf dk[4];
   DevBuf ex[16];
   DevBuf od[16];
+
+  PinRing pin;
 
   // timing
   bool timing = false;
@@ -147,7 +185,7 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   hipStream_t st = h->stream;
   HIPCHK(h, h->idx_bbox.reserve(6 * sizeof(int)));
   int init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
-  HIPCHK(h, hipMemcpyAsync(h->idx_bbox.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+  HIPCHK(h, h->pin.upload(h->idx_bbox.p, init, sizeof(init), st));
   const int blocks = std::min(div_up(n, 256), 2048);
   hipLaunchKernelGGL(grid_bbox_kernel, dim3(blocks), dim3(256), 0, st, pts, n, h->idx_bbox.as<int>());
   int bb[6];
@@ -219,9 +257,7 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
   }
   const int n_rec = offs[2 * (B + 1) + B];
   HIPCHK(h, h->in_off.reserve(offs.size() * sizeof(int)));
-  HIPCHK(h, hipMemcpyAsync(h->in_off.p, offs.data(), offs.size() * sizeof(int), hipMemcpyHostToDevice, st));
-  // the staging vector must outlive the async copy from pageable memory: hipMemcpyAsync from
-  // pageable host memory returns after the data has been staged, so this is safe.
+  HIPCHK(h, h->pin.upload(h->in_off.p, offs.data(), offs.size() * sizeof(int), st));
   HIPCHK(h, h->records.reserve(std::max<size_t>(1, (size_t)n_rec) * 6 * sizeof(double)));
   BatchView bv;
   bv.corner = d_corner; bv.corner_off = h->in_off.as<int>();
@@ -348,6 +384,7 @@ void msfl_destroy(msfl_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   collect_timing(h);
   for (auto e : h->free_events) (void)hipEventDestroy(e);
+  h->pin.release();
   DevBuf* bufs[] = {&h->map_c.sorted, &h->map_c.cell_start, &h->map_s.sorted, &h->map_s.cell_start, &h->in_corner,
                     &h->in_surf, &h->in_off, &h->poses, &h->status, &h->info, &h->records, &h->pprime,
                     &h->idx_cell_of, &h->idx_count, &h->idx_bbox, &h->idx_cub, &h->idx_stage};
@@ -362,7 +399,14 @@ void msfl_destroy(msfl_handle* h) {
 msfl_status msfl_set_stream(msfl_handle* h, void* hip_stream) {
   msfl_status s = enter(h); if (s) return s;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);   // NULL = HIP null stream
+  return MSFL_OK;
+}
+
+msfl_status msfl_reset_stream(msfl_handle* h) {
+  msfl_status s = enter(h); if (s) return s;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->stream = h->own_stream;
   return MSFL_OK;
 }
 
@@ -544,7 +588,7 @@ static msfl_status stage_single(msfl_handle* h, const msfl_point* corner, int n_
   HIPCHK(h, hipMemcpyAsync(h->poses.p, pose, 7 * sizeof(double), hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemsetAsync(h->status.p, 0, sizeof(int), st));
   const int offs[6] = {0, n_corner, 0, n_surf, 0, n_corner + n_surf};
-  HIPCHK(h, hipMemcpyAsync(h->in_off.p, offs, sizeof(offs), hipMemcpyHostToDevice, st));
+  HIPCHK(h, h->pin.upload(h->in_off.p, offs, sizeof(offs), st));
   bv.corner = h->in_corner.as<float4>(); bv.corner_off = h->in_off.as<int>();
   bv.surf = h->in_surf.as<float4>(); bv.surf_off = h->in_off.as<int>() + 2;
   bv.rec_off = h->in_off.as<int>() + 4;

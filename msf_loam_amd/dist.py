@@ -1,0 +1,91 @@
+"""Multi-GPU plumbing: scans shard embarrassingly across ranks (one process per GPU), the map is
+replicated, and the only data-path collective is the pose gather (RCCL all_gather over xGMI;
+`gloo` in the CPU tests).  SURVEY.md §8e.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, rank, world_size):
+    """Contiguous block partition [lo, hi) of n_items for `rank`; sizes differ by at most one."""
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_offsets(off, lo, hi):
+    """Slice a B+1 prefix-offset array to scans [lo, hi): (new offsets starting at 0, point range)."""
+    off = np.asarray(off)
+    return (off[lo:hi + 1] - off[lo]).astype(np.int32), (int(off[lo]), int(off[hi]))
+
+
+def broadcast_map(corner, surf, src=0, device=None):
+    """Replicate the local map (float32 (n,4) arrays) from `src` to every rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return corner, surf
+    dev = device or torch.device("cpu")
+    rank = dist.get_rank()
+    sizes = torch.tensor([len(corner) if rank == src else 0, len(surf) if rank == src else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(sizes, src)
+    out = []
+    for arr, n in ((corner, int(sizes[0])), (surf, int(sizes[1]))):
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(dev) if rank == src else torch.empty((n, 4), dtype=torch.float32, device=dev)
+        dist.broadcast(t, src)
+        out.append(t)
+    return out[0], out[1]
+
+
+class PoseGather:
+    """all_gather of per-rank (B,7) f64 poses + (B,) i32 status into (W,B,7) / (W,B) buffers.
+    Equal B on every rank (weak scaling); use gather_ragged for uneven shards."""
+
+    def __init__(self, B, device):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.poses = torch.empty((self.world, B, 7), dtype=torch.float64, device=device)
+        self.status = torch.empty((self.world, B), dtype=torch.int32, device=device)
+
+    def all_gather(self, poses, status):
+        if self.world == 1:
+            self.poses[0].copy_(poses); self.status[0].copy_(status)
+        else:
+            dist.all_gather_into_tensor(self.poses.view(-1), poses.reshape(-1))
+            dist.all_gather_into_tensor(self.status.view(-1), status.reshape(-1))
+        return self.poses, self.status
+
+
+def gather_ragged(poses, status, n_total):
+    """Gather block-partitioned results of uneven shards back into scan order on every rank."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return poses, status
+    dev = poses.device
+    cap = (n_total + world - 1) // world
+    pad_p = torch.zeros((cap, 7), dtype=torch.float64, device=dev); pad_p[:len(poses)] = poses
+    pad_s = torch.zeros((cap,), dtype=torch.int32, device=dev); pad_s[:len(status)] = status
+    all_p = torch.empty((world, cap, 7), dtype=torch.float64, device=dev)
+    all_s = torch.empty((world, cap), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(all_p.view(-1), pad_p.view(-1))
+    dist.all_gather_into_tensor(all_s.view(-1), pad_s.view(-1))
+    out_p, out_s = [], []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        out_p.append(all_p[r, :hi - lo]); out_s.append(all_s[r, :hi - lo])
+    return torch.cat(out_p), torch.cat(out_s)
+
+
+def register_sharded(register_fn, corner, corner_off, surf, surf_off, guesses):
+    """Shard B scans over the ranks, run `register_fn(corner, corner_off, surf, surf_off, guesses)
+    -> (poses (b,7), status (b,))` on the local block and gather everything in scan order.
+    `register_fn` is the device call (capi.Handle.match_scan2map_batch) in production."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    B = len(guesses)
+    lo, hi = shard_bounds(B, rank, world)
+    co, (c0, c1) = shard_offsets(corner_off, lo, hi)
+    so, (s0, s1) = shard_offsets(surf_off, lo, hi)
+    poses, status = register_fn(corner[c0:c1], co, surf[s0:s1], so, guesses[lo:hi])
+    p = torch.as_tensor(np.asarray(poses, dtype=np.float64).reshape(-1, 7))
+    s = torch.as_tensor(np.asarray(status, dtype=np.int32).reshape(-1))
+    gp, gs = gather_ragged(p, s, B)
+    return gp.numpy(), gs.numpy()
