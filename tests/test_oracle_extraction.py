@@ -1,0 +1,169 @@
+"""CPU tests pinning the oracle's feature extraction (msf_loam_node.cc:160-378) with an independent
+numpy formulation and hand-made known-answer sectors."""
+import numpy as np
+
+from msf_loam_amd import synth
+from tests import common
+
+
+def _np_curvature(cloud):
+    """f32 left-to-right 11-tap sum, f64 squares, f32 store (msf_loam_node.cc:213-240)."""
+    n = len(cloud)
+    out = np.zeros(n, np.float32)
+    xyz = cloud[:, :3].astype(np.float32)
+    acc = np.zeros((n - 10, 3), np.float32)
+    for k in (-5, -4, -3, -2, -1):
+        acc = (acc + xyz[5 + k:n - 5 + k]).astype(np.float32)
+    acc = (acc - (np.float32(10) * xyz[5:n - 5]).astype(np.float32)).astype(np.float32)
+    for k in (1, 2, 3, 4, 5):
+        acc = (acc + xyz[5 + k:n - 5 + k]).astype(np.float32)
+    d = acc.astype(np.float64)
+    out[5:n - 5] = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(np.float32)
+    return out
+
+
+def _np_relative_time(pts, ring):
+    ori = -np.arctan2(pts[:, 1].astype(np.float64), pts[:, 0].astype(np.float64))
+    rel = np.fmod(ori - ori[0] + 2 * np.pi, 2 * np.pi)
+    out = np.zeros(len(pts))
+    last = {}
+    for i in range(len(pts)):
+        r = int(ring[i]); v = rel[i]
+        if v < last.get(r, -1.0):
+            v += 2 * np.pi
+        last[r] = v
+        out[i] = v / (2 * np.pi) * 0.1
+    return out.astype(np.float32)
+
+
+def test_ring_concat_time_and_curvature(oracle):
+    pts, ring, _, _ = common.scans(1)[0]
+    f = oracle.extract_features(pts, ring)
+    assert f["rc"] == 0
+    # stable partition by ring
+    order = np.argsort(ring, kind="stable")
+    assert np.array_equal(f["ring"], ring[order])
+    assert np.array_equal(f["full"][:, :3], pts[order, :3])
+    t = _np_relative_time(pts, ring)[order]
+    assert np.abs(f["full"][:, 3] - t).max() <= 1.2e-7 * 0.1     # 1 ulp of f32 at 0.1 s
+    assert 0.0 <= f["full"][:, 3].min() and f["full"][:, 3].max() < 0.2
+    assert np.array_equal(f["curvature"], _np_curvature(f["full"]))
+
+
+def test_feature_sets_obey_the_pick_rules(oracle):
+    pts, ring, _, _ = common.scans(2)[1]
+    f = oracle.extract_features(pts, ring)
+    curv, label = f["curvature"], f["label"]
+    n_rings = int(ring.max()) + 1
+    assert len(f["sharp"]) <= 2 * 6 * n_rings and len(f["less_sharp"]) <= 20 * 6 * n_rings
+    assert len(f["flat"]) <= 4 * 6 * n_rings
+    assert np.all(curv[f["sharp"]] > 0.1) and np.all(curv[f["less_sharp"]] > 0.1) and np.all(curv[f["flat"]] < 0.1)
+    assert set(f["sharp"]).issubset(set(f["less_sharp"]))
+    assert np.all(label[f["sharp"]] == 1) and np.all(label[f["flat"]] == 3)
+    # less-flat is taken per sector BEFORE the next sector runs; the next sector's corner picks may
+    # relabel up to 5 trailing points of this sector LESS_SHARP afterwards (neighbour marking
+    # crosses sector boundaries, msf_loam_node.cc:298-303) -- the reference keeps them in less-flat.
+    late = f["less_flat"][~np.isin(label[f["less_flat"]], (0, 3))]
+    assert np.all(label[late] == 2) and len(late) < 0.01 * len(f["less_flat"])
+    for i in late:
+        assert np.any((f["less_sharp"] > i) & (f["less_sharp"] <= i + 5))
+    assert len(set(f["less_flat"])) == len(f["less_flat"]) and np.all(np.diff(f["less_flat"]) > 0)
+    # every sharp point is a local winner: no other sharp point within +-5 positions joined by small gaps
+    assert len(set(f["sharp"])) == len(f["sharp"])
+
+
+def _line_scan(n=400, ring_id=0):
+    """One ring along a straight wall: tiny, equal curvatures -> exercises ties + flat picks."""
+    pts = np.zeros((n, 4), np.float32)
+    ang = -np.linspace(0.0, 1.2, n)
+    pts[:, 0] = 10.0
+    pts[:, 1] = 10.0 * np.tan(ang)
+    return pts, np.full(n, ring_id, np.uint16)
+
+
+def test_known_answer_sector_with_a_corner_and_ties(oracle):
+    pts, ring = _line_scan()
+    # put a sharp depth discontinuity in the middle: points beyond k0 jump 3 m further away
+    k0 = 230          # mid-sector (sector 3 spans [199, 263]) so no other sector's marking interferes
+    pts[k0:, 0] += 3.0
+    f = oracle.extract_features(pts, ring)
+    assert f["rc"] == 0
+    n = len(pts)
+    start, end = 5, n - 6
+    # sector boundaries (msf_loam_node.cc:256-259)
+    sp = [start + (end - start) * j // 6 for j in range(6)]
+    ep = [start + (end - start) * (j + 1) // 6 - 1 for j in range(6)]
+    j0 = max(j for j in range(6) if sp[j] <= k0)
+    sharp_in = [i for i in f["sharp"] if sp[j0] <= i <= ep[j0]]
+    assert len(sharp_in) == 2
+    # the two sharp points sit on the two sides of the jump and are not suppressed by each other
+    # because the 3 m gap (gap^2 = 9 > 0.05) stops neighbour marking
+    assert any(i < k0 for i in sharp_in) and any(i >= k0 for i in sharp_in)
+    assert all(abs(i - k0) <= 6 for i in sharp_in)
+    # a flat wall sector: 4 flat picks, ties broken by ascending index in the oracle
+    flat0 = [i for i in f["flat"] if sp[0] <= i <= ep[0]]
+    assert len(flat0) == 4
+    curv = f["curvature"]
+    assert np.all(curv[flat0] < 0.1)
+    # neighbour suppression: with gaps^2 << 0.05, picks 1..3 mark +-5 so later picks are > 5 apart;
+    # the 4th pick happens BEFORE marking (break at :317), so only its distance to earlier picks matters
+    for a in range(3):
+        for b in range(a + 1, 4):
+            assert abs(flat0[a] - flat0[b]) > 5
+    # less-flat of sector 0 = everything not labelled LESS_SHARP/SHARP
+    lf0 = [i for i in f["less_flat"] if sp[0] <= i <= ep[0]]
+    assert len(lf0) == ep[0] - sp[0] + 1
+
+
+def test_neighbour_gap_breaks_suppression(oracle):
+    """Marking stops at the first consecutive gap with squared length > 0.05 (:293,300)."""
+    n = 300
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, 0] = 5.0
+    pts[:, 1] = np.arange(n) * 0.3          # 0.3 m spacing -> gap^2 = 0.09 > 0.05: no suppression at all
+    pts[170, 0] = 6.5                        # one spike mid-sector (sector 3 = [149, 196])
+    f = oracle.extract_features(pts, np.zeros(n, np.uint16))
+    # curvature: 225 at the spike, 2.25 (a 10-way tie) at its +-5 neighbours.  Without suppression
+    # the 2nd sharp pick is one of those neighbours: the highest index of the tie (descending scan
+    # over an ascending (curv, idx) order)
+    s = sorted(int(i) for i in f["sharp"] if 149 <= i <= 196)
+    assert s == [170, 175]
+    # now shrink the spacing so neighbours ARE suppressed (gap^2 = 0.0025 <= 0.05) up to the spike's
+    # own 1.5 m jumps.  Order: 170 (marks nothing, both gaps are jumps); 175 = top of the tie
+    # (marks 171..174 and 176..180, stops at the jump to 170); 169 = next unsuppressed of the tie
+    # (marks 164..168)
+    pts2 = pts.copy(); pts2[:, 1] = np.arange(n) * 0.05
+    f2 = oracle.extract_features(pts2, np.zeros(n, np.uint16))
+    s2 = sorted(int(i) for i in f2["less_sharp"] if 149 <= i <= 196)
+    assert s2 == [169, 170, 175]
+    assert sorted(int(i) for i in f2["sharp"] if 149 <= i <= 196) == [170, 175]
+
+
+def test_invalid_points_ring_errors_and_tiny_clouds(oracle):
+    pts, ring, _, _ = common.scans(1)[0]
+    p = pts.copy()
+    p[10, 0] = np.nan; p[11, :3] = 0.01; p[12, 1] = np.inf
+    f = oracle.extract_features(p, ring)
+    assert f["rc"] == 0 and len(f["full"]) == len(pts) - 3
+    r = ring.copy(); r[5] = 128
+    assert oracle.extract_features(pts, r)["rc"] == 5                      # CHECK_LT(ring, 128)
+    assert oracle.extract_features(np.zeros((0, 4), np.float32), np.zeros(0, np.uint16))["rc"] == 3
+    small = oracle.extract_features(pts[:8], ring[:8])
+    assert small["rc"] == 0 and len(small["sharp"]) == 0 and len(small["less_flat"]) == 0
+    # a ring with too few points for a sector (end - start < 6) yields nothing from that ring
+    few = np.concatenate([pts[ring == 0][:14]])
+    ff = oracle.extract_features(few, np.zeros(len(few), np.uint16))
+    assert ff["rc"] == 0 and len(ff["less_flat"]) == 0
+
+
+def test_extrinsic_is_applied_to_all_clouds(oracle):
+    pts, ring, _, _ = common.scans(1)[0]
+    ext = np.r_[0.5, -0.2, 0.1, synth.quat_from_euler(0.01, -0.02, 0.3)]
+    f0 = oracle.extract_features(pts, ring)
+    f1 = oracle.extract_features(pts, ring, extrinsic=ext)
+    for k in ("sharp", "less_sharp", "flat", "less_flat"):
+        assert np.array_equal(f0[k], f1[k])
+    want = np.stack([oracle.transform_point(ext, p[:3]) for p in f0["full"][:50]])
+    assert np.array_equal(f1["full"][:50, :3], want)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    assert np.array_equal(oracle.extract_features(pts, ring, extrinsic=ident)["full"], f0["full"])
