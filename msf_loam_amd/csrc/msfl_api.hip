@@ -186,7 +186,7 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   HIPCHK(h, h->idx_bbox.reserve(6 * sizeof(int)));
   int init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
   HIPCHK(h, h->pin.upload(h->idx_bbox.p, init, sizeof(init), st));
-  const int blocks = std::min(div_up(n, 256), 2048);
+  const int blocks = std::min(div_up(n, 256), 64);   // few blocks: the 6 atomics per wave contend on one line
   hipLaunchKernelGGL(grid_bbox_kernel, dim3(blocks), dim3(256), 0, st, pts, n, h->idx_bbox.as<int>());
   int bb[6];
   HIPCHK(h, hipMemcpyAsync(bb, h->idx_bbox.p, sizeof(bb), hipMemcpyDeviceToHost, st));

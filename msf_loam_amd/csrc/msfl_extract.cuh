@@ -1,2 +1,457 @@
-// msfl_extract.cuh — feature-extraction kernels (stage A). Filled in below.
+// msfl_extract.cuh — stage A: per-scan edge/plane feature extraction on gfx950.
+//
+// Replaces RealHandleLaserCloudMessage (msf_loam_node.cc:160-378).  Four kernels per batch:
+//   extract_prepare_kernel    one 1024-thread workgroup per scan: invalid-point removal (:85-111),
+//                             relative time (:128-156), stable split into rings + concat (:188-195)
+//   extract_curvature_kernel  one thread per point: 11-tap curvature (:213-240) + neighbour-gap flags
+//   extract_pick_kernel       one wavefront per (scan, ring): per-sector LDS bitonic sort of
+//                             (curvature, index) keys (:263-267) + the serial sharp / less-sharp / flat
+//                             pick with neighbour suppression on LDS bitmasks (:270-344)
+//   extract_compact_kernel    per scan: order the per-ring lists into the reference's push order,
+//                             apply the lidar->imu extrinsic (:367-371)
+// All index outputs are bit-exact w.r.t. the CPU oracle; the unstable std::sort tie order of the
+// reference is fixed to (curvature, index) ascending.
 #pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "msfl_math.cuh"
+
+namespace msfl {
+
+constexpr int kMaxRings = 128;          // kMaxScanNum, msf_loam_node.cc:79
+constexpr int kRingCapacity = 8192;     // points per ring handled by the LDS bitmasks
+constexpr int kSortLds = 512;           // sector sizes up to this sort in LDS, larger ones in global scratch
+
+struct ExtractParams {
+  double min_range;
+  double scan_period;
+  double curvature_threshold;   // compared as double against the f32 curvature (:275, :312)
+  double neighbor_gap_sq;       // compared as double against the f32 squared gap (:293)
+  int sectors, max_sharp, max_less_sharp, max_flat;
+};
+
+struct ExtractView {
+  // inputs (per scan b: [off[b], off[b+1]) )
+  const float4* in_pts; const uint16_t* in_ring; const int* off; int n_scans; int n_total;
+  // outputs at the same offsets
+  float4* full_pts; uint16_t* full_ring; float* curvature; uint8_t* label;
+  int* sharp_idx; int* less_sharp_idx; int* flat_idx; int* less_flat_idx;
+  int* n_full; int* n_sharp; int* n_less_sharp; int* n_flat; int* n_less_flat;
+  int* status;
+  // scratch
+  double* rel;                 // n_total: raw relative angle per output point
+  uint8_t* gap;                // n_total: 1 if |p[i+1]-p[i]|^2 > neighbor_gap_sq
+  int* ring_tab;               // n_scans x (kMaxRings + 1): ring start offsets (scan-local)
+  int* tmp_idx;                // 4 x n_total: per-ring lists before compaction
+  int* ring_cnt;               // n_scans x kMaxRings x 4
+  unsigned long long* sortbuf; // n_total: global fallback for sectors > kSortLds
+};
+
+__device__ __forceinline__ bool point_valid(float4 p, double min_range) {
+  // RemoveInvalidPointsFromCloud: getVector3fMap().norm() < min_range || !finite
+  const float nrm = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+  return !((double)nrm < min_range || !isfinite(p.x) || !isfinite(p.y) || !isfinite(p.z));
+}
+
+__global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, ExtractParams prm) {
+  __shared__ int s_cnt[kMaxRings];
+  __shared__ int s_off[kMaxRings + 1];
+  __shared__ int s_base[kMaxRings];
+  __shared__ int s_wrap[kMaxRings];
+  __shared__ int s_wavecnt[16][kMaxRings];
+  __shared__ int s_first, s_bad;
+  __shared__ double s_start_ori;
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int o = v.off[b];
+  const int n = v.off[b + 1] - o;
+  const float4* in = v.in_pts + o;
+  const uint16_t* in_ring = v.in_ring + o;
+  if (tid < kMaxRings) s_cnt[tid] = 0;
+  if (tid == 0) { s_first = 0x7fffffff; s_bad = 0; }
+  __syncthreads();
+  // P1: count valid points per ring, find the first valid point
+  for (int i = tid; i < n; i += 1024) {
+    const float4 p = in[i];
+    if (point_valid(p, prm.min_range)) {
+      const int r = in_ring[i];
+      if (r >= kMaxRings) s_bad = 1;                      // CHECK_LT(point.ring, 128), :136
+      else atomicAdd(&s_cnt[r], 1);
+      atomicMin(&s_first, i);
+    }
+  }
+  __syncthreads();
+  if (s_bad || s_first == 0x7fffffff) {
+    if (tid == 0) {
+      v.status[b] = s_bad ? 5 /*MSFL_BAD_RING*/ : 3 /*MSFL_BAD_ARG: empty valid cloud, CHECK :186,:200*/;
+      v.n_full[b] = 0; v.n_sharp[b] = 0; v.n_less_sharp[b] = 0; v.n_flat[b] = 0; v.n_less_flat[b] = 0;
+    }
+    if (tid <= kMaxRings) v.ring_tab[b * (kMaxRings + 1) + tid] = 0;
+    return;
+  }
+  // P2: ring offsets
+  if (tid == 0) {
+    int run = 0;
+    for (int r = 0; r < kMaxRings; r++) { s_off[r] = run; run += s_cnt[r]; }
+    s_off[kMaxRings] = run;
+    const float4 f = in[s_first];
+    s_start_ori = -atan2((double)f.y, (double)f.x);       // :131
+  }
+  __syncthreads();
+  if (tid <= kMaxRings) v.ring_tab[b * (kMaxRings + 1) + tid] = s_off[tid];
+  if (tid < kMaxRings) s_base[tid] = s_off[tid];
+  const int N = s_off[kMaxRings];
+  const double start_ori = s_start_ori;
+  const double two_pi = 2 * 3.14159265358979323846;
+  float4* out_pts = v.full_pts + o;
+  uint16_t* out_ring = v.full_ring + o;
+  double* rel = v.rel + o;
+  // P3: stable split into rings, chunk by chunk in driver order
+  for (int base = 0; base < n; base += 1024) {
+    for (int k = tid; k < 16 * kMaxRings; k += 1024) (&s_wavecnt[0][0])[k] = 0;
+    __syncthreads();
+    const int i = base + tid;
+    float4 p = make_float4(0, 0, 0, 0);
+    int r = -1;
+    bool valid = false;
+    if (i < n) {
+      p = in[i];
+      valid = point_valid(p, prm.min_range);
+      if (valid) r = in_ring[i];
+    }
+    int rank = 0;
+    unsigned long long remaining = __ballot(valid);
+    while (remaining) {
+      const int leader = __ffsll((long long)remaining) - 1;
+      const int lead_ring = __shfl(r, leader);
+      const unsigned long long m = __ballot(valid && r == lead_ring);
+      if (valid && r == lead_ring) rank = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == leader) s_wavecnt[wave][lead_ring] = __popcll(m);
+      remaining &= ~m;
+    }
+    __syncthreads();
+    if (tid < kMaxRings) {
+      int run = s_base[tid];
+#pragma unroll
+      for (int w = 0; w < 16; w++) { const int t = s_wavecnt[w][tid]; s_wavecnt[w][tid] = run; run += t; }
+      s_base[tid] = run;
+    }
+    __syncthreads();
+    if (valid) {
+      const int dst = s_wavecnt[wave][r] + rank;
+      const double ori = -atan2((double)p.y, (double)p.x);                 // :139
+      rel[dst] = fmod(ori - start_ori + two_pi, two_pi);                   // :142
+      out_pts[dst] = make_float4(p.x, p.y, p.z, 0.f);
+      out_ring[dst] = (uint16_t)r;
+    }
+    __syncthreads();
+  }
+  // P4: per ring, the first point whose raw angle is below its predecessor's: from there on the
+  // reference adds 2 pi (a prefix-OR of `relative_angle < last_relative_angles[ring]`, :145-149)
+  if (tid < kMaxRings) s_wrap[tid] = 0x7fffffff;
+  __syncthreads();
+  for (int i = tid; i < N; i += 1024) {
+    const int r = out_ring[i];
+    if (i > s_off[r] && rel[i] < rel[i - 1]) atomicMin(&s_wrap[r], i);
+  }
+  __syncthreads();
+  // P5: relative time (stored in both `time` and `intensity`, :152-153)
+  for (int i = tid; i < N; i += 1024) {
+    const int r = out_ring[i];
+    double a = rel[i];
+    if (i >= s_wrap[r]) a += two_pi;
+    const double t = a / two_pi * prm.scan_period;                         // :151
+    out_pts[i].w = (float)t;
+  }
+  if (tid == 0) v.n_full[b] = N;
+}
+
+__device__ __forceinline__ int find_scan_off(const int* __restrict__ off, int n_scans, int g) {
+  int lo = 0, hi = n_scans;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (off[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256) extract_curvature_kernel(ExtractView v, ExtractParams prm) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= v.n_total) return;
+  const int b = find_scan_off(v.off, v.n_scans, g);
+  const int o = v.off[b];
+  const int i = g - o;
+  const int N = v.n_full[b];
+  if (i >= N) return;
+  const float4* c = v.full_pts + o;
+  float curv = 0.f;
+  if (i >= 5 && i < N - 5) {
+    // f32 sums in source order (:214-234), f64 squares, f32 store (:236)
+    const float4 m5 = c[i - 5], m4 = c[i - 4], m3 = c[i - 3], m2 = c[i - 2], m1 = c[i - 1], p0 = c[i];
+    const float4 p1 = c[i + 1], p2 = c[i + 2], p3 = c[i + 3], p4 = c[i + 4], p5 = c[i + 5];
+    const float dx = m5.x + m4.x + m3.x + m2.x + m1.x - 10 * p0.x + p1.x + p2.x + p3.x + p4.x + p5.x;
+    const float dy = m5.y + m4.y + m3.y + m2.y + m1.y - 10 * p0.y + p1.y + p2.y + p3.y + p4.y + p5.y;
+    const float dz = m5.z + m4.z + m3.z + m2.z + m1.z - 10 * p0.z + p1.z + p2.z + p3.z + p4.z + p5.z;
+    const double X = dx, Y = dy, Z = dz;
+    curv = (float)(X * X + Y * Y + Z * Z);
+  }
+  v.curvature[g] = curv;
+  v.label[g] = 0;
+  uint8_t gp = 1;
+  if (i + 1 < N) {
+    const float4 a = c[i + 1], q = c[i];
+    const float ex = a.x - q.x, ey = a.y - q.y, ez = a.z - q.z;
+    const float s = ex * ex + ey * ey + ez * ez;           // Vector3f squaredNorm
+    gp = ((double)s > prm.neighbor_gap_sq) ? 1 : 0;        // :293,300,326,332
+  }
+  v.gap[g] = gp;
+}
+
+// ---- wave-level bitonic sort of 64-bit keys (ascending) ----------------------------------------
+// keys[0..P) with P a power of two; every lane of the wave takes part.
+template <class KeyPtr>
+__device__ __forceinline__ void wave_bitonic_sort(KeyPtr keys, int P, int lane) {
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < (P >> 1); t += 64) {
+        // t-th compare-exchange pair of this stage
+        const int lo = ((t / j) * (j << 1)) + (t % j);
+        const int hi = lo + j;
+        const bool up = ((lo & k) == 0);
+        const unsigned long long a = keys[lo], c = keys[hi];
+        if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
+struct RingBits {
+  unsigned int* w;   // LDS words
+  __device__ __forceinline__ bool get(int i) const { return (w[i >> 5] >> (i & 31)) & 1u; }
+  __device__ __forceinline__ void set(int i) { w[i >> 5] |= (1u << (i & 31)); }
+};
+
+__global__ void __launch_bounds__(256) extract_pick_kernel(ExtractView v, ExtractParams prm) {
+  __shared__ unsigned long long s_keys[4][kSortLds];
+  __shared__ unsigned int s_picked[4][kRingCapacity / 32];
+  __shared__ unsigned int s_corner[4][kRingCapacity / 32];
+  __shared__ unsigned int s_gap[4][kRingCapacity / 32];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= kMaxRings) return;
+  int* cnt_out = v.ring_cnt + ((size_t)b * kMaxRings + r) * 4;
+  const int* tab = v.ring_tab + b * (kMaxRings + 1);
+  const int s = tab[r], len = tab[r + 1] - tab[r];
+  const int o = v.off[b];
+  int n_sharp = 0, n_ls = 0, n_flat = 0, n_lf = 0;
+  const int start = s + 5, end = s + len - 6;                               // :192-194
+  const bool active = (v.status[b] == 0) && len > 0 && (end - start >= 6);  // :252
+  if (!active) {
+    if (lane == 0) { cnt_out[0] = 0; cnt_out[1] = 0; cnt_out[2] = 0; cnt_out[3] = 0; }
+    return;
+  }
+  if (len > kRingCapacity) {
+    if (lane == 0) { v.status[b] = 7 /*MSFL_CAPACITY*/; cnt_out[0] = cnt_out[1] = cnt_out[2] = cnt_out[3] = 0; }
+    return;
+  }
+  const float* curv = v.curvature + o;
+  uint8_t* label = v.label + o;
+  const uint8_t* gapb = v.gap + o;
+  int* t_sharp = v.tmp_idx + 0 * (size_t)v.n_total + o + s;
+  int* t_ls = v.tmp_idx + 1 * (size_t)v.n_total + o + s;
+  int* t_flat = v.tmp_idx + 2 * (size_t)v.n_total + o + s;
+  int* t_lf = v.tmp_idx + 3 * (size_t)v.n_total + o + s;
+  RingBits picked{s_picked[wave]}, corner{s_corner[wave]}, gap{s_gap[wave]};
+  // ring-local bitmasks: bit k <-> scan-local index s + k
+  for (int w0 = 0; w0 < len; w0 += 64) {
+    const int k = w0 + lane;
+    const bool gbit = (k < len) ? (gapb[s + k] != 0) : true;
+    const unsigned long long m = __ballot(gbit);
+    if (lane == 0) {
+      gap.w[(w0 >> 5)] = (unsigned int)m; gap.w[(w0 >> 5) + 1] = (unsigned int)(m >> 32);
+      picked.w[(w0 >> 5)] = 0; picked.w[(w0 >> 5) + 1] = 0;
+      corner.w[(w0 >> 5)] = 0; corner.w[(w0 >> 5) + 1] = 0;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  unsigned long long* gkeys = v.sortbuf + o + s;      // global fallback region of this ring (len entries)
+  for (int j = 0; j < prm.sectors; j++) {
+    const int sp = start + (end - start) * j / prm.sectors;                 // :256-259
+    const int ep = start + (end - start) * (j + 1) / prm.sectors - 1;
+    const int cnt = ep - sp + 1;
+    if (cnt <= 0) continue;
+    int P = 1;
+    while (P < cnt) P <<= 1;
+    const bool in_lds = (P <= kSortLds);
+    // keys: (curvature bits << 32) | index.  curvature >= 0, so the f32 bit pattern is monotone and
+    // the u64 order is exactly (curvature, index) ascending.
+    if (in_lds) {
+      unsigned long long* keys = s_keys[wave];
+      for (int k = lane; k < P; k += 64)
+        keys[k] = (k < cnt) ? (((unsigned long long)__float_as_uint(curv[sp + k]) << 32) | (unsigned int)(sp + k)) : ~0ull;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wave_bitonic_sort(keys, P, lane);
+    } else {
+      // P <= 2*cnt - 1 <= len holds for every sector of a ring that passed the `end-start >= 6` gate
+      for (int k = lane; k < P; k += 64)
+        gkeys[k] = (k < cnt) ? (((unsigned long long)__float_as_uint(curv[sp + k]) << 32) | (unsigned int)(sp + k)) : ~0ull;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      wave_bitonic_sort(gkeys, P, lane);
+    }
+    if (lane == 0) {
+      const unsigned long long* keys = in_lds ? s_keys[wave] : gkeys;
+      // corner picks, descending curvature (:272-305)
+      int largest = 0;
+      for (int k = cnt - 1; k >= 0; k--) {
+        const unsigned long long key = keys[k];
+        const int ind = (int)(unsigned int)key;
+        const float c = __uint_as_float((unsigned int)(key >> 32));
+        if (!((double)c > prm.curvature_threshold)) break;   // sorted: nothing below can qualify
+        const int q = ind - s;
+        if (picked.get(q)) continue;
+        largest++;
+        if (largest <= prm.max_sharp) {
+          label[ind] = 1; t_sharp[n_sharp++] = ind; t_ls[n_ls++] = ind;
+        } else if (largest <= prm.max_less_sharp) {
+          label[ind] = 2; t_ls[n_ls++] = ind;
+        } else {
+          break;
+        }
+        picked.set(q); corner.set(q);
+        for (int l = 1; l <= 5; l++) {
+          if (gap.get(q + l - 1)) break;                     // |p[ind+l] - p[ind+l-1]|^2 > 0.05
+          picked.set(q + l); corner.set(q + l); label[ind + l] = 2;
+        }
+        for (int l = -1; l >= -5; l--) {
+          if (gap.get(q + l)) break;                         // |p[ind+l] - p[ind+l+1]|^2 > 0.05
+          picked.set(q + l); corner.set(q + l); label[ind + l] = 2;
+        }
+      }
+      // flat picks, ascending curvature (:307-336)
+      int smallest = 0;
+      for (int k = 0; k < cnt; k++) {
+        const unsigned long long key = keys[k];
+        const int ind = (int)(unsigned int)key;
+        const float c = __uint_as_float((unsigned int)(key >> 32));
+        if (!((double)c < prm.curvature_threshold)) break;
+        const int q = ind - s;
+        if (picked.get(q)) continue;
+        label[ind] = 3; t_flat[n_flat++] = ind;
+        smallest++;
+        if (smallest >= prm.max_flat) break;                 // before neighbour marking, :317-319
+        picked.set(q);
+        for (int l = 1; l <= 5; l++) { if (gap.get(q + l - 1)) break; picked.set(q + l); }
+        for (int l = -1; l >= -5; l--) { if (gap.get(q + l)) break; picked.set(q + l); }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // less-flat = positions of this sector not labelled SHARP / LESS_SHARP so far (:338-344)
+    n_lf = __shfl(n_lf, 0);
+    for (int k0 = sp; k0 <= ep; k0 += 64) {
+      const int k = k0 + lane;
+      const bool keep = (k <= ep) && !corner.get(k - s);
+      const unsigned long long m = __ballot(keep);
+      if (keep) t_lf[n_lf + __popcll(m & ((1ull << lane) - 1ull))] = k;
+      n_lf += __popcll(m);
+    }
+  }
+  if (lane == 0) { cnt_out[0] = n_sharp; cnt_out[1] = n_ls; cnt_out[2] = n_flat; cnt_out[3] = n_lf; }
+}
+
+__global__ void __launch_bounds__(256) extract_compact_kernel(ExtractView v, const double* __restrict__ extrinsic) {
+  __shared__ int s_pref[4][kMaxRings + 1];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int o = v.off[b];
+  const int* cnt = v.ring_cnt + (size_t)b * kMaxRings * 4;
+  const int* tab = v.ring_tab + b * (kMaxRings + 1);
+  const bool ok = (v.status[b] == 0);
+  if (tid < 4) {
+    int run = 0;
+    for (int r = 0; r < kMaxRings; r++) { s_pref[tid][r] = run; run += ok ? cnt[r * 4 + tid] : 0; }
+    s_pref[tid][kMaxRings] = run;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    v.n_sharp[b] = s_pref[0][kMaxRings]; v.n_less_sharp[b] = s_pref[1][kMaxRings];
+    v.n_flat[b] = s_pref[2][kMaxRings]; v.n_less_flat[b] = s_pref[3][kMaxRings];
+    if (!ok) v.n_full[b] = (v.status[b] == 7) ? v.n_full[b] : 0;
+  }
+  if (!ok) return;
+  int* outs[4] = {v.sharp_idx + o, v.less_sharp_idx + o, v.flat_idx + o, v.less_flat_idx + o};
+#pragma unroll
+  for (int L = 0; L < 4; L++) {
+    const int* tmp = v.tmp_idx + (size_t)L * v.n_total + o;
+    for (int r = 0; r < kMaxRings; r++) {
+      const int c = cnt[r * 4 + L];
+      const int dst = s_pref[L][r], src = tab[r];
+      for (int k = tid; k < c; k += 256) outs[L][dst + k] = tmp[src + k];
+    }
+  }
+  // TransformPointCloudInPlace x5 (:367-371): the five clouds are gathers of the full cloud
+  if (extrinsic) {
+    const pose7 T = load_pose(extrinsic);
+    const int N = v.n_full[b];
+    float4* c = v.full_pts + o;
+    for (int i = tid; i < N; i += 256) {
+      const float4 p = c[i];
+      const float3 t = transform_point_f32(T, p.x, p.y, p.z);
+      c[i] = make_float4(t.x, t.y, t.z, p.w);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pcl::VoxelGrid centroid filter (laser_mapping.cc:264-270) — caller-side helper, SURVEY.md §8f N2
+// ---------------------------------------------------------------------------------------------
+struct VoxelDesc { float inv_leaf; int min_b[3]; int div_b[3]; };
+
+__global__ void __launch_bounds__(256) voxel_key_kernel(const float4* __restrict__ pts, int n, VoxelDesc d,
+                                                         unsigned long long* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  const int i0 = (int)(floorf(p.x * d.inv_leaf) - (float)d.min_b[0]);
+  const int i1 = (int)(floorf(p.y * d.inv_leaf) - (float)d.min_b[1]);
+  const int i2 = (int)(floorf(p.z * d.inv_leaf) - (float)d.min_b[2]);
+  const unsigned long long cell = (unsigned long long)((long long)i0 + (long long)i1 * d.div_b[0] +
+                                                       (long long)i2 * d.div_b[0] * (long long)d.div_b[1]);
+  keys[i] = (cell << 32) | (unsigned int)i;     // sort by (voxel, point index): stable order inside a voxel
+}
+
+__global__ void __launch_bounds__(256) voxel_flag_kernel(const unsigned long long* __restrict__ keys, int n, int* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flag[i] = (i == 0 || (keys[i] >> 32) != (keys[i - 1] >> 32)) ? 1 : 0;
+}
+
+// pos[i] = inclusive scan of flag; one thread per voxel head accumulates its run sequentially in f32
+// (pcl CentroidPoint accumulators) and writes the centroid.
+__global__ void __launch_bounds__(256) voxel_centroid_kernel(const float4* __restrict__ pts, const unsigned long long* __restrict__ keys,
+                                                              const int* __restrict__ flag, const int* __restrict__ pos, int n,
+                                                              float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  const unsigned long long cell = keys[i] >> 32;
+  float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
+  int j = i;
+  for (; j < n && (keys[j] >> 32) == cell; j++) {
+    const float4 p = pts[(unsigned int)keys[j]];
+    sx += p.x; sy += p.y; sz += p.z; st += p.w;
+  }
+  const float c = (float)(j - i);
+  out[pos[i] - 1] = make_float4(sx / c, sy / c, sz / c, st / c);
+}
+
+}  // namespace msfl

@@ -1,2 +1,182 @@
-// msfl_odom.cuh — scan-to-scan association kernels (stage B). Filled in below.
+// msfl_odom.cuh — stage B: scan-to-scan data association on gfx950.
+//
+// Replaces the two association loops of OdometryScanMatcher::MatchScan2Scan
+// (odometry_scan_matcher.cc:81-163 edges, :166-258 planes).  The solve is the same persistent
+// LM kernel as stage C (lm_solve_kernel) with the `< 10 correspondences` gate (:262-267).
+//
+// One 256-thread workgroup per (scan pair, tile of 256 query features).  The target cloud of the
+// previous scan (<= 1 920 less-sharp / ~20-26 k less-flat points) is streamed through LDS in
+// 1024-point tiles that all queries of the workgroup share (ds_read broadcast), twice:
+//   pass 1  exact 1-NN (replaces the kd-tree query :84 / :169; f32 L2_Simple distances, ties -> lower index)
+//   pass 2  the two ring-window scans, restated as one ascending sweep with the reference's
+//           visit-order semantics (forward scan first, strict '<' updates, break at the first
+//           out-of-window ring in each direction).
 #pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "msfl_kernels.cuh"
+
+namespace msfl {
+
+struct OdomView {
+  // previous scan (targets), concatenated over the batch
+  const float4* last_ls; const uint16_t* last_ls_ring; const int* last_ls_off;
+  const float4* last_lf; const uint16_t* last_lf_ring; const int* last_lf_off;
+  double dist_sq_threshold;   // kDistanceSqThreshold = 25
+  double nearby_scan;         // kNearByScan = 2.5
+};
+
+constexpr int kOdomTile = 1024;
+
+__device__ __forceinline__ float odom_dist(float4 a, float3 q) {
+  // (ax-qx)*(ax-qx) + (ay-qy)*(ay-qy) + (az-qz)*(az-qz) in f32 (:102-108); same order as L2_Simple
+  const float dx = a.x - q.x, dy = a.y - q.y, dz = a.z - q.z;
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// bv.corner = curr sharp, bv.surf = curr flat; records in feature order (sharp first).
+__global__ void __launch_bounds__(256)
+assoc_scan2scan_kernel(BatchView bv, OdomView ov, const double* __restrict__ poses, const int* __restrict__ status,
+                       double* __restrict__ rec) {
+  __shared__ float4 s_tile[kOdomTile];
+  const int b = blockIdx.y;
+  const int n_sharp = bv.corner_off[b + 1] - bv.corner_off[b];
+  const int n_flat = bv.surf_off[b + 1] - bv.surf_off[b];
+  const int nq = n_sharp + n_flat;
+  const int q0 = blockIdx.x * 256;
+  if (q0 >= nq) return;
+  const int qi = q0 + threadIdx.x;
+  const bool has_q = qi < nq;
+  double* out = rec + 6 * ((size_t)bv.rec_off[b] + qi);
+  if (status[b] != 0) {
+    if (has_q) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) out[k] = 0.0;
+    }
+    return;
+  }
+  const bool is_edge = has_q && qi < n_sharp;
+  const bool is_plane = has_q && !is_edge;
+  float4 f = make_float4(0, 0, 0, 0);
+  float3 q = make_float3(0, 0, 0);
+  if (has_q) {
+    f = is_edge ? bv.corner[bv.corner_off[b] + qi] : bv.surf[bv.surf_off[b] + (qi - n_sharp)];
+    const pose7 T = load_pose(poses + 7 * b);
+    q = transform_point_f32(T, f.x, f.y, f.z);        // TransformToStart with s = 1 (:21-33)
+  }
+  const float thr = (float)ov.dist_sq_threshold;
+  // which target clouds does this workgroup need? (uniform)
+  const bool wg_has_edge = q0 < n_sharp;
+  const bool wg_has_plane = (q0 + 256 > n_sharp) && (nq > n_sharp);
+  int closest = -1, min2 = -1, min3 = -1;
+
+  for (int which = 0; which < 2; which++) {
+    const bool edge_pass = (which == 0);
+    if (edge_pass ? !wg_has_edge : !wg_has_plane) continue;
+    const float4* tp = edge_pass ? ov.last_ls + ov.last_ls_off[b] : ov.last_lf + ov.last_lf_off[b];
+    const uint16_t* tr = edge_pass ? ov.last_ls_ring + ov.last_ls_off[b] : ov.last_lf_ring + ov.last_lf_off[b];
+    const int nt = edge_pass ? ov.last_ls_off[b + 1] - ov.last_ls_off[b] : ov.last_lf_off[b + 1] - ov.last_lf_off[b];
+    const bool mine = edge_pass ? is_edge : is_plane;
+    // ---- pass 1: exact 1-NN ----
+    float best = INFINITY; int besti = -1;
+    for (int t0 = 0; t0 < nt; t0 += kOdomTile) {
+      __syncthreads();
+      for (int k = threadIdx.x; k < kOdomTile; k += 256) {
+        const int j = t0 + k;
+        if (j < nt) { float4 p = tp[j]; p.w = __int_as_float((int)tr[j]); s_tile[k] = p; }
+      }
+      __syncthreads();
+      if (mine) {
+        const int m = min(kOdomTile, nt - t0);
+        for (int k = 0; k < m; k++) {
+          const float d = odom_dist(s_tile[k], q);
+          if (d < best) { best = d; besti = t0 + k; }
+        }
+      }
+    }
+    // ---- pass 2: ring-window sweep ----
+    int id = 0;
+    bool go = mine && besti >= 0 && best < thr;            // :87 / :173
+    if (go) { closest = besti; id = tr[besti]; }
+    const float hi_ring = (float)id + (float)ov.nearby_scan, lo_ring = (float)id - (float)ov.nearby_scan;
+    float b2F = thr, b2B = thr, b3F = thr, b3B = thr;
+    int i2F = -1, i2B = -1, i3F = -1, i3B = -1;
+    bool fwd_done = false;
+    for (int t0 = 0; t0 < nt; t0 += kOdomTile) {
+      __syncthreads();
+      for (int k = threadIdx.x; k < kOdomTile; k += 256) {
+        const int j = t0 + k;
+        if (j < nt) { float4 p = tp[j]; p.w = __int_as_float((int)tr[j]); s_tile[k] = p; }
+      }
+      __syncthreads();
+      if (go) {
+        const int m = min(kOdomTile, nt - t0);
+        for (int k = 0; k < m; k++) {
+          const int j = t0 + k;
+          if (j == closest) continue;
+          const float4 p = s_tile[k];
+          const int rj = __float_as_int(p.w);
+          if (j > closest) {
+            // forward scan (:93-115 / :183-207)
+            if (fwd_done) continue;
+            if (edge_pass) {
+              if (rj <= id) continue;
+              if ((float)rj > hi_ring) { fwd_done = true; continue; }
+              const float d = odom_dist(p, q);
+              if (d < b2F) { b2F = d; i2F = j; }
+            } else {
+              if ((float)rj > hi_ring) { fwd_done = true; continue; }
+              const float d = odom_dist(p, q);
+              if (rj <= id) { if (d < b2F) { b2F = d; i2F = j; } }
+              else { if (d < b3F) { b3F = d; i3F = j; } }
+            }
+          } else {
+            // backward scan (:118-140 / :210-232), visited here in ascending order: a break point
+            // invalidates everything below it, and among equal distances the later (larger) index
+            // is the one the descending scan meets first
+            if (edge_pass) {
+              if (rj >= id) continue;
+              if ((float)rj < lo_ring) { b2B = thr; i2B = -1; continue; }
+              const float d = odom_dist(p, q);
+              if (d < b2B || (d == b2B && i2B >= 0)) { b2B = d; i2B = j; }
+            } else {
+              if ((float)rj < lo_ring) { b2B = thr; i2B = -1; b3B = thr; i3B = -1; continue; }
+              const float d = odom_dist(p, q);
+              if (rj >= id) { if (d < b2B || (d == b2B && i2B >= 0)) { b2B = d; i2B = j; } }
+              else { if (d < b3B || (d == b3B && i3B >= 0)) { b3B = d; i3B = j; } }
+            }
+          }
+        }
+      }
+    }
+    if (go) {
+      // the backward scan continues the forward scan's running minimum with strict '<'
+      min2 = (i2B >= 0 && b2B < b2F) ? i2B : i2F;
+      if (!edge_pass) min3 = (i3B >= 0 && b3B < b3F) ? i3B : i3F;
+      d3 C = mk3(0, 0, 0), N = mk3(0, 0, 0);
+      if (edge_pass) {
+        if (min2 >= 0) {                                                   // :143-162
+          const float4 a = tp[closest], c = tp[min2];
+          const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z);
+          N = normalized(A - Bp);
+          C = A;
+        }
+      } else {
+        if (min2 >= 0 && min3 >= 0) {                                      // :234-256, lidar_factor.h:70-78
+          const float4 a = tp[closest], c = tp[min2], e = tp[min3];
+          const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z),
+                   Cp = mk3((double)e.x, (double)e.y, (double)e.z);
+          N = normalized(cross(A - Bp, A - Cp));
+          C = mk3((A.x + Bp.x + Cp.x) / 3, (A.y + Bp.y + Cp.y) / 3, (A.z + Bp.z + Cp.z) / 3);
+        }
+      }
+      out[0] = C.x; out[1] = C.y; out[2] = C.z; out[3] = N.x; out[4] = N.y; out[5] = N.z;
+    } else if (mine) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) out[k] = 0.0;
+    }
+  }
+}
+
+}  // namespace msfl

@@ -1,0 +1,99 @@
+"""GPU parity of stage A (feature extraction) and the voxel helper against the CPU oracle.
+Integer/index outputs must be BIT-EXACT; curvature is f32-exact; relative time within 1 ulp(f32)
+(device atan2 vs libm)."""
+import numpy as np
+import pytest
+
+from msf_loam_amd import capi, synth
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(f, fo):
+    assert f["rc"] == fo["rc"]
+    assert np.array_equal(f["ring"], fo["ring"])
+    assert np.array_equal(f["full"][:, :3], fo["full"][:, :3])
+    assert np.array_equal(f["curvature"], fo["curvature"])
+    assert np.array_equal(f["label"], fo["label"])
+    for k in ("sharp", "less_sharp", "flat", "less_flat"):
+        assert np.array_equal(f[k], fo[k]), k
+    dt = np.abs(f["full"][:, 3].astype(np.float64) - fo["full"][:, 3].astype(np.float64))
+    assert dt.max() <= np.spacing(np.float32(0.2)), dt.max()
+    assert np.mean(f["full"][:, 3] == fo["full"][:, 3]) > 0.99
+
+
+def test_single_scan_bit_exact(gpu, oracle):
+    for pts, ring, _, _ in common.scans(3):
+        _check(gpu.extract_features(pts, ring), oracle.extract_features(pts, ring))
+
+
+def test_batch_ragged_bit_exact(gpu, oracle):
+    sc = common.scans(5)
+    # ragged: different sizes, one shuffled-ring-order scan, one with invalid points
+    clouds = []
+    for i, (pts, ring, _, _) in enumerate(sc):
+        p, r = pts.copy(), ring.copy()
+        if i == 1:
+            p, r = p[: len(p) // 2], r[: len(r) // 2]
+        if i == 2:
+            p[100:140, 0] = np.nan; p[500:520, :3] = 0.05
+        if i == 3:
+            rng = np.random.default_rng(3)
+            keep = rng.uniform(size=len(p)) > 0.3          # drop points -> ragged rings
+            p, r = p[keep], r[keep]
+        clouds.append((p, r))
+    off = np.cumsum([0] + [len(p) for p, _ in clouds]).astype(np.int32)
+    res = gpu.extract_features_batch(np.concatenate([p for p, _ in clouds]), np.concatenate([r for _, r in clouds]), off)
+    for (p, r), f in zip(clouds, res):
+        _check(f, oracle.extract_features(p, r))
+
+
+def test_hand_made_ties_and_gap_breaks(gpu, oracle):
+    n = 300
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, 0] = 5.0
+    pts[:, 1] = np.arange(n) * 0.05
+    pts[170, 0] = 6.5
+    ring = np.zeros(n, np.uint16)
+    _check(gpu.extract_features(pts, ring), oracle.extract_features(pts, ring))
+    pts[:, 1] = np.arange(n) * 0.3
+    _check(gpu.extract_features(pts, ring), oracle.extract_features(pts, ring))
+    # perfectly flat wall: every curvature ties
+    pts2 = np.zeros((400, 4), np.float32); pts2[:, 0] = 10.0; pts2[:, 1] = np.linspace(-4, 4, 400)
+    _check(gpu.extract_features(pts2, np.zeros(400, np.uint16)), oracle.extract_features(pts2, np.zeros(400, np.uint16)))
+
+
+def test_big_sector_uses_global_sort_fallback(gpu, oracle):
+    """A ring with > 6*512 points forces the global-memory sort path."""
+    rng = np.random.default_rng(11)
+    n = 5000
+    ang = -np.linspace(0, 2 * np.pi, n, endpoint=False)
+    rad = 10 + rng.normal(0, 0.02, n) + (np.sin(ang * 40) > 0.95) * 1.5
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, 0] = rad * np.cos(ang); pts[:, 1] = rad * np.sin(ang); pts[:, 2] = rng.normal(0, 0.01, n)
+    _check(gpu.extract_features(pts, np.zeros(n, np.uint16)), oracle.extract_features(pts, np.zeros(n, np.uint16)))
+
+
+def test_extrinsic_and_error_statuses(gpu, oracle):
+    pts, ring, _, _ = common.scans(1)[0]
+    ext = np.r_[0.5, -0.2, 0.1, synth.quat_from_euler(0.01, -0.02, 0.3)]
+    f, fo = gpu.extract_features(pts, ring, extrinsic=ext), oracle.extract_features(pts, ring, extrinsic=ext)
+    _check(f, fo)
+    r = ring.copy(); r[5] = 128
+    assert gpu.extract_features(pts, r, allow=(capi.BAD_RING,))["rc"] == capi.BAD_RING
+    bad = pts.copy(); bad[:, :3] = np.nan
+    assert gpu.extract_features(bad, ring, allow=(capi.BAD_ARG,))["rc"] == capi.BAD_ARG
+    small = gpu.extract_features(pts[:8], ring[:8])
+    assert small["rc"] == 0 and len(small["sharp"]) == 0 and len(small["less_flat"]) == 0 and len(small["full"]) == 8
+
+
+def test_voxel_downsample_matches_oracle(gpu, oracle):
+    pts, ring, _, _ = common.scans(1)[0]
+    f = oracle.extract_features(pts, ring)
+    for cloud, leaf in ((f["full"][f["less_sharp"]], 0.2), (f["full"][f["less_flat"]], 0.4), (f["full"], 0.4)):
+        g = gpu.voxel_downsample(cloud, leaf)
+        o = oracle.voxel_grid(cloud, leaf)
+        assert g.shape == o.shape
+        assert np.array_equal(g, o), np.abs(g - o).max()
+    assert len(gpu.voxel_downsample(np.zeros((0, 4), np.float32), 0.2)) == 0

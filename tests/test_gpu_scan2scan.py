@@ -1,0 +1,87 @@
+"""GPU parity of stage B (scan-to-scan registration) against the CPU oracle through the C ABI."""
+import numpy as np
+import pytest
+
+from msf_loam_amd import capi, synth
+from tests import common
+
+pytestmark = pytest.mark.gpu
+TIGHT = 1e-7
+
+
+def _pair(oracle, i):
+    """Two consecutive scans of a slow trajectory + the oracle's features for both."""
+    w, _, _ = common.small_world()
+    base = synth.random_poses(8, synth.SEED + 77)[i]
+    rng = np.random.default_rng(100 + i)
+    nxt = synth.perturb_pose(base, rng, 0.25, 2.0)
+    pa, ra = synth.make_scan(w, base, 9000 + i)
+    pb, rb = synth.make_scan(w, nxt, 9100 + i)
+    fa, fb = oracle.extract_features(pa, ra), oracle.extract_features(pb, rb)
+    return fa, fb
+
+
+def _clouds(fa, fb):
+    return (fa["full"][fa["less_sharp"]], fa["ring"][fa["less_sharp"]], fa["full"][fa["less_flat"]], fa["ring"][fa["less_flat"]],
+            fb["full"][fb["sharp"]], fb["full"][fb["flat"]])
+
+
+def test_pose_parity_and_counts(gpu, oracle):
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    for i in range(4):
+        fa, fb = _pair(oracle, i)
+        c = _clouds(fa, fb)
+        rc, pose_o, info_o = oracle.match_scan2scan(*c, ident)
+        s, pose_g, info_g = gpu.match_scan2scan(*c, ident)
+        assert s == rc == 0
+        assert list(info_g.n_edge) == list(info_o.n_edge) and list(info_g.n_plane) == list(info_o.n_plane)
+        assert list(info_g.lm_iterations) == list(info_o.lm_iterations)
+        dt, dr = synth.pose_error(pose_g, pose_o)
+        assert dt < 1e-4 and dr < 1e-4
+        assert dt < TIGHT and dr < TIGHT, (dt, dr)
+        assert info_o.n_edge[0] > 20 and info_o.n_plane[0] > 100
+
+
+def test_batch_and_too_few_correspondences(gpu, oracle):
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    pairs = [_clouds(*_pair(oracle, i)) for i in range(3)]
+    # pair 1 gets a hopeless guess: 1-NN beyond 5 m everywhere -> < 10 correspondences -> false (:262-267)
+    guesses = np.stack([ident, np.array([500.0, 0, 0, 0, 0, 0, 1.0]), ident])
+    sets = []
+    for k in range(4):
+        pts = np.concatenate([p[k if k < 2 else k + 2] if False else (p[0], p[2], p[4], p[5])[k] for p in pairs])
+        off = np.cumsum([0] + [len((p[0], p[2], p[4], p[5])[k]) for p in pairs]).astype(np.int32)
+        ring = np.concatenate([(p[1], p[3])[k] for p in pairs]) if k < 2 else None
+        sets.append((pts, ring, off))
+    poses, status, info = gpu.match_scan2scan_batch(sets, guesses, want_info=True)
+    assert list(status) == [0, capi.TOO_FEW_CORRESPONDENCES, 0]
+    assert np.array_equal(poses[1], guesses[1]), "a failed scan keeps its pose"
+    for b in (0, 2):
+        rc, pose_o, _ = oracle.match_scan2scan(*pairs[b], guesses[b])
+        assert rc == 0
+        dt, dr = synth.pose_error(poses[b], pose_o)
+        assert dt < TIGHT and dr < TIGHT
+    rc, pose_o, _ = oracle.match_scan2scan(*pairs[1], guesses[1])
+    assert rc == 1 and np.array_equal(pose_o, guesses[1])
+    s, p, _ = gpu.match_scan2scan(*pairs[1], guesses[1])
+    assert s == capi.TOO_FEW_CORRESPONDENCES
+
+
+def test_unsorted_rings_follow_reference_break_semantics(gpu, oracle):
+    """The window scans `break` at the first out-of-window ring; on a cloud that is NOT ring-sorted
+    that differs from a ring filter.  Shuffle the previous scan's feature order and compare."""
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    fa, fb = _pair(oracle, 5)
+    c = list(_clouds(fa, fb))
+    rng = np.random.default_rng(5)
+    for k in (0, 2):
+        perm = rng.permutation(len(c[k]))
+        blocks = np.array_split(perm, 40)              # shuffle blocks: locally ordered, globally not
+        perm = np.concatenate([np.sort(b) for b in blocks])
+        c[k], c[k + 1] = c[k][perm], c[k + 1][perm]
+    rc, pose_o, info_o = oracle.match_scan2scan(*c, ident)
+    s, pose_g, info_g = gpu.match_scan2scan(*c, ident)
+    assert s == rc
+    assert list(info_g.n_edge) == list(info_o.n_edge) and list(info_g.n_plane) == list(info_o.n_plane)
+    dt, dr = synth.pose_error(pose_g, pose_o)
+    assert dt < TIGHT and dr < TIGHT
