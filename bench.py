@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--scans", type=int, default=1024, help="scans per GPU per step (BASELINE configs[1]: 1024)")
     ap.add_argument("--map-points", type=int, default=200000)
     ap.add_argument("--cpu-sample", type=int, default=128, help="scans timed on the CPU oracle (0 disables)")
-    ap.add_argument("--features", choices=["product", "direct"], default="direct",
+    ap.add_argument("--features", choices=["product", "direct"], default="product",
                     help="product: features from the GPU extraction + voxel kernels; direct: from ray-cast hit kinds")
     args = ap.parse_args()
 
@@ -203,7 +203,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "assoc_scan2map_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes_assoc, "avg_launch_ms": assoc_ms},
-            "kernels_ms": {"assoc": assoc_ms, "solve": solve_ms, "index_build": index_ms,
+            "kernels_ms": {"assoc": assoc_ms, "fit": timing.ms_fit / max(timing.launches_fit, 1), "solve": solve_ms,
+                           "index_build": index_ms,
                            "launches": {"assoc": timing.launches_assoc, "solve": timing.launches_solve,
                                         "index": timing.launches_index}},
             "prep_s": t_prep,

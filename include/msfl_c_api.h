@@ -118,11 +118,12 @@ typedef struct msfl_match_info {
 /* Accumulated GPU time per kernel class, measured with HIP events on the handle's stream
    (enabled by msfl_set_timing).  Used by bench.py for the live roofline figure. */
 typedef struct msfl_timing {
-  int    launches_assoc;   double ms_assoc;     /* kNN + line/plane fit kernel        */
+  int    launches_assoc;   double ms_assoc;     /* transform + exact 5-NN kernel      */
   int    launches_solve;   double ms_solve;     /* persistent LM + Huber solve kernel */
   int    launches_index;   double ms_index;     /* map grid index build (all kernels) */
   int    launches_extract; double ms_extract;   /* feature extraction (all kernels)   */
   int    launches_odom;    double ms_odom;      /* scan-to-scan association kernel    */
+  int    launches_fit;     double ms_fit;       /* line / plane fit kernel            */
 } msfl_timing;
 
 /* ------------------------------------------------------------------------------------------ */

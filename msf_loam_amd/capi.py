@@ -54,7 +54,8 @@ class Timing(C.Structure):
                 ("launches_solve", C.c_int), ("ms_solve", C.c_double),
                 ("launches_index", C.c_int), ("ms_index", C.c_double),
                 ("launches_extract", C.c_int), ("ms_extract", C.c_double),
-                ("launches_odom", C.c_int), ("ms_odom", C.c_double)]
+                ("launches_odom", C.c_int), ("ms_odom", C.c_double),
+                ("launches_fit", C.c_int), ("ms_fit", C.c_double)]
 
 
 class Deskew(C.Structure):

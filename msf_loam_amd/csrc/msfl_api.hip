@@ -82,7 +82,7 @@ struct MapIndex {
   int n_input = 0;    // points handed to msfl_set_map
 };
 
-enum TimerClass { T_ASSOC = 0, T_SOLVE, T_INDEX, T_EXTRACT, T_ODOM, T_COUNT };
+enum TimerClass { T_ASSOC = 0, T_SOLVE, T_INDEX, T_EXTRACT, T_ODOM, T_FIT, T_COUNT };
 
 struct TimedSpan { hipEvent_t a, b; int cls; };
 
@@ -99,7 +99,7 @@ struct msfl_handle_s {
   MapIndex map_c, map_s;
 
   // scratch
-  DevBuf in_corner, in_surf, in_off, poses, status, info, records, pprime;
+  DevBuf in_corner, in_surf, in_off, poses, status, info, records, pprime, nn;
   DevBuf idx_cell_of, idx_count, idx_bbox, idx_cub, idx_stage;
   DevBuf dk[4];
   DevBuf ex[16];
@@ -241,6 +241,38 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   return MSFL_OK;
 }
 
+// one data-association pass = kNN kernel + fit kernel
+void s_launch_assoc(msfl_handle* h, const BatchView& bv, const double* d_poses, const int* d_status, bool deskew,
+                    const DeskewView& dv, int n_rec) {
+  hipStream_t st = h->stream;
+  int* nn = h->nn.as<int>();
+  const dim3 grid(div_up(n_rec, 256)), block(256);
+  {
+    ScopedTimer timer(h, T_ASSOC);
+    if (deskew)
+      hipLaunchKernelGGL(knn5_scan2map_kernel<true>, grid, block, 0, st, bv, d_poses, d_status,
+                         h->map_c.g, h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                         h->map_s.g, h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                         h->prm.map_knn_max_sq_dist, dv, nn);
+    else
+      hipLaunchKernelGGL(knn5_scan2map_kernel<false>, grid, block, 0, st, bv, d_poses, d_status,
+                         h->map_c.g, h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                         h->map_s.g, h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                         h->prm.map_knn_max_sq_dist, dv, nn);
+  }
+  {
+    ScopedTimer timer(h, T_FIT);
+    if (deskew)
+      hipLaunchKernelGGL(fit_scan2map_kernel<true>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(),
+                         h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
+                         h->records.as<double>());
+    else
+      hipLaunchKernelGGL(fit_scan2map_kernel<false>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(),
+                         h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
+                         h->records.as<double>());
+  }
+}
+
 // Core of stage C.  All pointers are device pointers except the offsets (host).
 msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner, const int* h_corner_off,
                                   const float4* d_surf, const int* h_surf_off, double* d_poses, int* d_status,
@@ -259,6 +291,7 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
   HIPCHK(h, h->in_off.reserve(offs.size() * sizeof(int)));
   HIPCHK(h, h->pin.upload(h->in_off.p, offs.data(), offs.size() * sizeof(int), st));
   HIPCHK(h, h->records.reserve(std::max<size_t>(1, (size_t)n_rec) * 6 * sizeof(double)));
+  HIPCHK(h, h->nn.reserve(std::max<size_t>(1, (size_t)n_rec) * 5 * sizeof(int)));
   BatchView bv;
   bv.corner = d_corner; bv.corner_off = h->in_off.as<int>();
   bv.surf = d_surf; bv.surf_off = h->in_off.as<int>() + (B + 1);
@@ -273,20 +306,7 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
   const SolverParams sp = solver_params(h->prm, 0);
   for (int it = 0; it < h->prm.outer_iterations; it++) {
     if (n_rec > 0) {
-      ScopedTimer timer(h, T_ASSOC);
-      if (deskew) {
-        hipLaunchKernelGGL(assoc_scan2map_kernel<true>, dim3(div_up(n_rec, 256)), dim3(256), 0, st, bv, d_poses, d_status,
-                           h->map_c.g, h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
-                           h->map_s.g, h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
-                           h->prm.map_knn_max_sq_dist, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
-                           h->records.as<double>());
-      } else {
-        hipLaunchKernelGGL(assoc_scan2map_kernel<false>, dim3(div_up(n_rec, 256)), dim3(256), 0, st, bv, d_poses, d_status,
-                           h->map_c.g, h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
-                           h->map_s.g, h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
-                           h->prm.map_knn_max_sq_dist, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
-                           h->records.as<double>());
-      }
+      s_launch_assoc(h, bv, d_poses, d_status, deskew != nullptr, dv, n_rec);
     }
     {
       ScopedTimer timer(h, T_SOLVE);
@@ -386,7 +406,7 @@ void msfl_destroy(msfl_handle* h) {
   for (auto e : h->free_events) (void)hipEventDestroy(e);
   h->pin.release();
   DevBuf* bufs[] = {&h->map_c.sorted, &h->map_c.cell_start, &h->map_s.sorted, &h->map_s.cell_start, &h->in_corner,
-                    &h->in_surf, &h->in_off, &h->poses, &h->status, &h->info, &h->records, &h->pprime,
+                    &h->in_surf, &h->in_off, &h->poses, &h->status, &h->info, &h->records, &h->pprime, &h->nn,
                     &h->idx_cell_of, &h->idx_count, &h->idx_bbox, &h->idx_cub, &h->idx_stage};
   for (auto* b : bufs) b->release();
   for (auto& b : h->dk) b.release();
@@ -448,6 +468,7 @@ msfl_status msfl_get_timing(msfl_handle* h, msfl_timing* out, int reset) {
   out->launches_index = h->t_n[T_INDEX];     out->ms_index = h->t_ms[T_INDEX];
   out->launches_extract = h->t_n[T_EXTRACT]; out->ms_extract = h->t_ms[T_EXTRACT];
   out->launches_odom = h->t_n[T_ODOM];       out->ms_odom = h->t_ms[T_ODOM];
+  out->launches_fit = h->t_n[T_FIT];         out->ms_fit = h->t_ms[T_FIT];
   if (reset) for (int i = 0; i < T_COUNT; i++) { h->t_ms[i] = 0; h->t_n[i] = 0; }
   return MSFL_OK;
 }
@@ -583,6 +604,7 @@ static msfl_status stage_single(msfl_handle* h, const msfl_point* corner, int n_
   HIPCHK(h, h->status.reserve(sizeof(int)));
   HIPCHK(h, h->in_off.reserve(6 * sizeof(int)));
   HIPCHK(h, h->records.reserve(std::max<size_t>(1, (size_t)(n_corner + n_surf)) * 6 * sizeof(double)));
+  HIPCHK(h, h->nn.reserve(std::max<size_t>(1, (size_t)(n_corner + n_surf)) * 5 * sizeof(int)));
   if (n_corner) HIPCHK(h, hipMemcpyAsync(h->in_corner.p, corner, (size_t)n_corner * sizeof(float4), hipMemcpyHostToDevice, st));
   if (n_surf) HIPCHK(h, hipMemcpyAsync(h->in_surf.p, surf, (size_t)n_surf * sizeof(float4), hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemcpyAsync(h->poses.p, pose, 7 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -607,15 +629,7 @@ msfl_status msfl_associate_scan2map(msfl_handle* h, const msfl_point* corner, in
   BatchView bv;
   s = stage_single(h, corner, n_corner, surf, n_surf, pose, bv); if (s) return s;
   DeskewView dv{};
-  {
-    ScopedTimer timer(h, T_ASSOC);
-    hipLaunchKernelGGL(assoc_scan2map_kernel<false>, dim3(div_up(n, 256)), dim3(256), 0, h->stream, bv,
-                       (const double*)h->poses.as<double>(), (const int*)h->status.as<int>(),
-                       h->map_c.g, h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
-                       h->map_s.g, h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
-                       h->prm.map_knn_max_sq_dist, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
-                       h->records.as<double>());
-  }
+  s_launch_assoc(h, bv, h->poses.as<double>(), h->status.as<int>(), false, dv, n);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(records_out, h->records.p, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));

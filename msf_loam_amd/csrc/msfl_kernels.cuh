@@ -152,26 +152,53 @@ __device__ __forceinline__ float l2_simple(float4 a, float3 q) {
   return r;
 }
 
+// Exact 5-NN over the 27-cell neighbourhood.  Rows (y,z) are visited centre-first and a row / an
+// end cell of a row is skipped when a LOWER BOUND of its distance to the query already exceeds the
+// current 5th-best distance, so the result is identical to scanning all 27 cells.  The bound is
+// shrunk by 1e-3 cell to stay conservative under the f32 rounding of cell coordinates.
+__device__ __forceinline__ float axis_gap(float u, int c) {
+  // distance (in cell units) from coordinate u to the interval [c, c+1], minus slack, floored at 0
+  const float g = fmaxf((float)c - u, u - (float)(c + 1));
+  return fmaxf(g - 1e-3f, 0.0f);
+}
+
 __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __restrict__ sorted,
                                           const int* __restrict__ cell_start, float3 q, Top5& t) {
   t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = INFINITY;
   t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0x7fffffff;
   t.p0 = t.p1 = t.p2 = t.p3 = t.p4 = -1;
+  const float ux = (q.x - g.ox) * g.inv_cell, uy = (q.y - g.oy) * g.inv_cell, uz = (q.z - g.oz) * g.inv_cell;
   const int cx = grid_coord(q.x, g.ox, g.inv_cell, g.dx);
   const int cy = grid_coord(q.y, g.oy, g.inv_cell, g.dy);
   const int cz = grid_coord(q.z, g.oz, g.inv_cell, g.dz);
   const int xs = max(cx - 1, 0), xe = min(cx + 1, g.dx - 1);
   if (xs > xe) return;
-  for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); z++) {
-    for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); y++) {
-      const int row = (z * g.dy + y) * g.dx;
-      // the three x-adjacent cells are contiguous in the sorted array: one range per (y, z)
-      const int s = cell_start[row + xs], e = cell_start[row + xe + 1];
-      for (int k = s; k < e; k++) {
-        const float4 m = sorted[k];
-        top5_insert(t, l2_simple(m, q), __float_as_int(m.w), k);
-      }
+  const float cell = 1.0f / g.inv_cell;
+  const float cell2 = cell * cell;
+  // visit order of the 9 (dy,dz) rows: centre, 4 edge neighbours, 4 diagonal neighbours (value + 1, 2 bits each)
+  constexpr unsigned DY = 1u | (0u << 2) | (2u << 4) | (1u << 6) | (1u << 8) | (0u << 10) | (2u << 12) | (0u << 14) | (2u << 16);
+  constexpr unsigned DZ = 1u | (1u << 2) | (1u << 4) | (0u << 6) | (2u << 8) | (0u << 10) | (0u << 12) | (2u << 14) | (2u << 16);
+  for (int r = 0; r < 9; r++) {
+    const int y = cy + (int)((DY >> (2 * r)) & 3u) - 1;
+    const int z = cz + (int)((DZ >> (2 * r)) & 3u) - 1;
+    if (y < 0 || y >= g.dy || z < 0 || z >= g.dz) continue;
+    const float gy = axis_gap(uy, y), gz = axis_gap(uz, z);
+    const float row2 = (gy * gy + gz * gz) * cell2;
+    if (row2 > t.d4) continue;
+    // trim the x range: drop an end cell whose lower bound exceeds the 5th-best distance
+    int a = xs, b = xe;
+    { const float gx = axis_gap(ux, a); if (a < b && row2 + gx * gx * cell2 > t.d4) a++; }
+    { const float gx = axis_gap(ux, b); if (a < b && row2 + gx * gx * cell2 > t.d4) b--; }
+    const int row = (z * g.dy + y) * g.dx;
+    // x-adjacent cells are contiguous in the sorted array: one range per (y, z)
+    const int s = cell_start[row + a], e = cell_start[row + b + 1];
+    int k = s;
+    for (; k + 1 < e; k += 2) {            // two loads in flight
+      const float4 m0 = sorted[k], m1 = sorted[k + 1];
+      top5_insert(t, l2_simple(m0, q), __float_as_int(m0.w), k);
+      top5_insert(t, l2_simple(m1, q), __float_as_int(m1.w), k + 1);
     }
+    if (k < e) { const float4 m = sorted[k]; top5_insert(t, l2_simple(m, q), __float_as_int(m.w), k); }
   }
 }
 
@@ -253,22 +280,20 @@ struct DeskewView {
   double* pprime;           // out: n_records x 3, p' = dq*p + dp
 };
 
+// K4a: transform + exact 5-NN.  Low register count (no f64 fits here) -> 8 waves/SIMD to hide the
+// latency of the scattered 16-byte candidate loads.  nn[5*g..] = positions in the sorted map array,
+// nn[5*g] = -1 when the feature is rejected by the `pointSearchSqDis[4] < 1.0` gate (:128 / :198).
 template <bool DESKEW>
 __global__ void __launch_bounds__(256)
-assoc_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
-                      GridDesc gc, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
-                      GridDesc gs, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
-                      float max_sq_dist, double line_ratio, double plane_tol,
-                      DeskewView dv, double* __restrict__ rec) {
+knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
+                     GridDesc gc, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
+                     GridDesc gs, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
+                     float max_sq_dist, DeskewView dv, int* __restrict__ nn) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bv.n_records) return;
   const int b = find_scan(bv.rec_off, bv.n_scans, g);
-  double* out = rec + 6 * (size_t)g;
-  if (status[b] != 0) {   // scan already failed: leave an empty record
-#pragma unroll
-    for (int k = 0; k < 6; k++) out[k] = 0.0;
-    return;
-  }
+  int* out = nn + 5 * (size_t)g;
+  if (status[b] != 0) { out[0] = -1; return; }
   const int local = g - bv.rec_off[b];
   const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
   const bool is_edge = local < nc;
@@ -276,7 +301,6 @@ assoc_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int*
   const float4 f = is_edge ? bv.corner[fi] : bv.surf[fi];
   const pose7 T = load_pose(poses + 7 * b);
   float3 q;
-  d3 shift = mk3(0, 0, 0);
   if (DESKEW) {
     // mapping_scan_matcher.cc:120 / :190: pose * Rigid3d{q^-1 (Vi dt - G dt^2/2) + dp, dq}
     const double* dqp = is_edge ? dv.corner_dq + 4 * (size_t)fi : dv.surf_dq + 4 * (size_t)fi;
@@ -284,8 +308,8 @@ assoc_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int*
     quat dq; dq.x = dqp[0]; dq.y = dqp[1]; dq.z = dqp[2]; dq.w = dqp[3];
     const d3 dp = mk3(dpp[0], dpp[1], dpp[2]);
     const double dt = (double)f.w;
-    shift = mk3(dv.V[0] * dt - 0.5 * dv.G[0] * dt * dt, dv.V[1] * dt - 0.5 * dv.G[1] * dt * dt,
-                dv.V[2] * dt - 0.5 * dv.G[2] * dt * dt);
+    const d3 shift = mk3(dv.V[0] * dt - 0.5 * dv.G[0] * dt * dt, dv.V[1] * dt - 0.5 * dv.G[1] * dt * dt,
+                         dv.V[2] * dt - 0.5 * dv.G[2] * dt * dt);
     quat qc; qc.x = -T.q.x; qc.y = -T.q.y; qc.z = -T.q.z; qc.w = T.q.w;
     pose7 full;
     full.t = quat_rotate(T.q, quat_rotate(qc, shift) + dp) + T.t;       // Rigid3d operator*
@@ -298,12 +322,40 @@ assoc_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int*
   }
   Top5 t;
   if (is_edge) knn5_grid(gc, map_c, cs_c, q, t); else knn5_grid(gs, map_s, cs_s, q, t);
-  FitOut fo; fo.ok = false; fo.C = mk3(0, 0, 0); fo.N = mk3(0, 0, 0);
   if (t.p4 >= 0 && (double)t.d4 < (double)max_sq_dist) {                // :128 / :198
+    out[0] = t.p0; out[1] = t.p1; out[2] = t.p2; out[3] = t.p3; out[4] = t.p4;
+  } else {
+    out[0] = -1;
+  }
+}
+
+// K4b: 5 neighbours -> line fit (3x3 Jacobi eigen) / plane fit (5x3 Householder QR) -> {C, N} record
+template <bool DESKEW>
+__global__ void __launch_bounds__(256)
+fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
+                    const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
+                    double* __restrict__ rec) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= bv.n_records) return;
+  double* out = rec + 6 * (size_t)g;
+  const int* in = nn + 5 * (size_t)g;
+  FitOut fo; fo.ok = false; fo.C = mk3(0, 0, 0); fo.N = mk3(0, 0, 0);
+  const int p0 = in[0];
+  if (p0 >= 0) {
+    const int b = find_scan(bv.rec_off, bv.n_scans, g);
+    const int local = g - bv.rec_off[b];
+    const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
+    const bool is_edge = local < nc;
     const float4* mp = is_edge ? map_c : map_s;
-    const float4 nb[5] = {mp[t.p0], mp[t.p1], mp[t.p2], mp[t.p3], mp[t.p4]};
+    const float4 nb[5] = {mp[p0], mp[in[1]], mp[in[2]], mp[in[3]], mp[in[4]]};
     fo = is_edge ? edge_fit(nb, line_ratio) : plane_fit(nb, plane_tol);
-    if (DESKEW && fo.ok) fo.C = fo.C - shift;   // C' = C - (Vi dt - G dt^2/2), velocity block constant (.cc:94)
+    if (DESKEW && fo.ok) {
+      // C' = C - (Vi dt - G dt^2/2): the velocity block is constant (mapping_scan_matcher.cc:94)
+      const int fi = is_edge ? bv.corner_off[b] + local : bv.surf_off[b] + (local - nc);
+      const double dt = (double)(is_edge ? bv.corner[fi].w : bv.surf[fi].w);
+      fo.C = fo.C - mk3(dv.V[0] * dt - 0.5 * dv.G[0] * dt * dt, dv.V[1] * dt - 0.5 * dv.G[1] * dt * dt,
+                        dv.V[2] * dt - 0.5 * dv.G[2] * dt * dt);
+    }
   }
   out[0] = fo.C.x; out[1] = fo.C.y; out[2] = fo.C.z;
   out[3] = fo.N.x; out[4] = fo.N.y; out[5] = fo.N.z;
@@ -332,20 +384,23 @@ struct DevMatchInfo {   // mirrors msfl_match_info
 
 constexpr int kAcc = 28;   // cost + g[6] + H upper[21]
 
-// row of the (robustified) Jacobian: a = d r/d t (3), rotation part b = -M^T a, residual ra
-__device__ __forceinline__ void acc_row(double (&acc)[kAcc], const mat3& M, d3 a, double ra, double sc) {
-  const double b0 = -(M.m[0] * a.x + M.m[3] * a.y + M.m[6] * a.z);
-  const double b1 = -(M.m[1] * a.x + M.m[4] * a.y + M.m[7] * a.z);
-  const double b2 = -(M.m[2] * a.x + M.m[5] * a.y + M.m[8] * a.z);
-  const double j[6] = {sc * a.x, sc * a.y, sc * a.z, sc * b0, sc * b1, sc * b2};
+// row of the (robustified) Jacobian: a = d r/d t (3); rotation part b = -(R skew(p))^T a
+// = p x (R^T a)  (lidar_factor.cc:19,39 in closed form); residual ra; sc = sqrt(rho')
+__device__ __forceinline__ void acc_row(double (&acc)[kAcc], const mat3& R, d3 p, d3 a, double ra, double sc) {
+#pragma clang fp contract(fast)   // accumulation only: fused multiply-adds, parity is a 1e-4 bar
+  const d3 l = mk3(R.m[0] * a.x + R.m[3] * a.y + R.m[6] * a.z,
+                   R.m[1] * a.x + R.m[4] * a.y + R.m[7] * a.z,
+                   R.m[2] * a.x + R.m[5] * a.y + R.m[8] * a.z);
+  const d3 b = cross(p, l);
+  const double j[6] = {sc * a.x, sc * a.y, sc * a.z, sc * b.x, sc * b.y, sc * b.z};
   const double r = sc * ra;
 #pragma unroll
   for (int k = 0; k < 6; k++) acc[1 + k] += j[k] * r;
   int n = 7;
 #pragma unroll
-  for (int p = 0; p < 6; p++)
+  for (int p2 = 0; p2 < 6; p2++)
 #pragma unroll
-    for (int q = p; q < 6; q++) acc[n++] += j[p] * j[q];
+    for (int q = p2; q < 6; q++) acc[n++] += j[p2] * j[q];
 }
 
 __device__ __forceinline__ void huber_rho(double a, double s, double& rho0, double& rho1) {
@@ -387,11 +442,6 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
       p = mk3((double)f.x, (double)f.y, (double)f.z);          // curr_point: untransformed (:146, :221)
     }
     const d3 d = quat_rotate(T.q, p) + T.t - C;
-    // M = R * skew(p)
-    mat3 M;
-    M.m[0] = R.m[1] * p.z - R.m[2] * p.y; M.m[1] = -R.m[0] * p.z + R.m[2] * p.x; M.m[2] = R.m[0] * p.y - R.m[1] * p.x;
-    M.m[3] = R.m[4] * p.z - R.m[5] * p.y; M.m[4] = -R.m[3] * p.z + R.m[5] * p.x; M.m[5] = R.m[3] * p.y - R.m[4] * p.x;
-    M.m[6] = R.m[7] * p.z - R.m[8] * p.y; M.m[7] = -R.m[6] * p.z + R.m[8] * p.x; M.m[8] = R.m[6] * p.y - R.m[7] * p.x;
     if (is_edge) {
       n_edge++;
       const d3 r = cross(N, d);                                // lidar_factor.cc:12
@@ -399,18 +449,28 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
       double rho0, rho1; huber_rho(huber, s, rho0, rho1);
       acc[0] += 0.5 * rho0;
       const double sc = sqrt(rho1);
-      acc_row(acc, M, mk3(0.0, -N.z, N.y), r.x, sc);           // rows of skew(N), :18-19
-      acc_row(acc, M, mk3(N.z, 0.0, -N.x), r.y, sc);
-      acc_row(acc, M, mk3(-N.y, N.x, 0.0), r.z, sc);
+      acc_row(acc, R, p, mk3(0.0, -N.z, N.y), r.x, sc);        // rows of skew(N), :18-19
+      acc_row(acc, R, p, mk3(N.z, 0.0, -N.x), r.y, sc);
+      acc_row(acc, R, p, mk3(-N.y, N.x, 0.0), r.z, sc);
     } else {
       n_plane++;
       const double r = dot(N, d);                              // lidar_factor.cc:32
       double rho0, rho1; huber_rho(huber, r * r, rho0, rho1);
       acc[0] += 0.5 * rho0;
-      acc_row(acc, M, N, r, sqrt(rho1));                       // :38-39
+      acc_row(acc, R, p, N, r, sqrt(rho1));                    // :38-39
     }
   }
 }
+
+// Trust-region state of one solve.  Lives in LDS so that the evaluation passes (which every lane
+// runs) keep a small register footprint; only lane 0 of the workgroup touches it.
+struct TrState {
+  double sys[kAcc];          // {cost, g, H upper} at the current iterate x
+  double scale[6], diagonal[6];
+  double x[7], cand[7];
+  double cost, gmax, x_norm, radius, decrease_factor, model_cost_change;
+  int iteration, invalid, successful, reuse_diagonal, step_ok;
+};
 
 template <int BLOCK>
 struct LmShared {
@@ -418,8 +478,7 @@ struct LmShared {
   double red[kAcc];          // reduced {cost, g, H} of the last pass
   int    cnt_part[BLOCK / 64][2];
   int    cnt[2];
-  double x[7];               // current iterate
-  double cand[7];            // candidate
+  TrState tr;
   int    go;                 // 1: evaluate candidate, 0: finished
 };
 
@@ -493,7 +552,7 @@ __device__ __forceinline__ bool chol_solve6(const double (&A)[6][6], const doubl
   return ok;
 }
 
-__device__ __forceinline__ double gradient_max_norm(const pose7& x, const double (&g)[6]) {
+__device__ __forceinline__ double gradient_max_norm(const pose7& x, const double* g) {
   const pose7 xp = pose_plus(x, mk3(-g[0], -g[1], -g[2]), mk3(-g[3], -g[4], -g[5]));
   double m = fabs(x.t.x - xp.t.x);
   m = fmax(m, fabs(x.t.y - xp.t.y)); m = fmax(m, fabs(x.t.z - xp.t.z));
@@ -505,23 +564,154 @@ __device__ __forceinline__ double pose_norm(const pose7& x) {
   return sqrt(x.t.x * x.t.x + x.t.y * x.t.y + x.t.z * x.t.z + x.q.x * x.q.x + x.q.y * x.q.y + x.q.z * x.q.z + x.q.w * x.q.w);
 }
 
-// unpack the reduced accumulator into full H (6x6), g
-__device__ __forceinline__ void unpack_system(const double* red, double (&H)[6][6], double (&g)[6]) {
+// unpack the packed accumulator into full H (6x6), g
+__device__ __forceinline__ void unpack_system(const double* sys, double (&H)[6][6], double (&g)[6]) {
 #pragma unroll
-  for (int k = 0; k < 6; k++) g[k] = red[1 + k];
+  for (int k = 0; k < 6; k++) g[k] = sys[1 + k];
   int n = 7;
 #pragma unroll
   for (int p = 0; p < 6; p++)
 #pragma unroll
-    for (int q = p; q < 6; q++) { H[p][q] = red[n]; H[q][p] = red[n]; n++; }
+    for (int q = p; q < 6; q++) { H[p][q] = sys[n]; H[q][p] = sys[n]; n++; }
+}
+
+// FinalizeIterationAndCheckIfMinimizerCanContinue + ComputeTrustRegionStep (+ HandleInvalidStep,
+// ParameterToleranceReached), lane 0 only.  Returns 1 when tr.cand holds a candidate to evaluate.
+__device__ __noinline__ int tr_propose(TrState& tr, const SolverParams& prm) {
+  for (;;) {
+    if (tr.iteration >= prm.max_iterations) return 0;
+    if (tr.step_ok && tr.gmax <= prm.gtol) return 0;
+    if (tr.radius < prm.radius_min) return 0;
+    tr.iteration++;
+    // One 6x6 live at a time: A = S H S (+ LM damping), factorised in place.
+    double A[6][6], gs[6], y[6], lm2[6];
+    {
+      int n = 7;
+#pragma unroll
+      for (int p = 0; p < 6; p++)
+#pragma unroll
+        for (int q = p; q < 6; q++) { const double v = tr.sys[n++] * tr.scale[p] * tr.scale[q]; A[p][q] = v; A[q][p] = v; }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) gs[i] = tr.sys[1 + i] * tr.scale[i];
+    if (!tr.reuse_diagonal) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) tr.diagonal[i] = fmin(fmax(A[i][i], prm.min_diag), prm.max_diag);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const double lm = sqrt(tr.diagonal[i] / tr.radius);
+      lm2[i] = lm * lm;
+      A[i][i] += lm2[i];
+    }
+    // step^T Hs step = step^T A step - sum lm2 step^2 is evaluated BEFORE the in-place factorisation
+    // destroys A, which needs the step first: so solve on a copy-free path: factorise, solve, then
+    // rebuild the quadratic form from the packed system.
+    double L[6][6];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        double s = A[i][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+        if (i == j) { if (!(s > 0.0)) ok = false; L[i][i] = sqrt(s); }
+        else L[i][j] = s / L[j][j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double s = gs[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) s -= L[i][k] * y[k];
+      y[i] = s / L[i][i];
+    }
+    double step[6];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+      double s = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; k++) s -= L[k][i] * step[k];
+      step[i] = s / L[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { if (!isfinite(step[i])) ok = false; step[i] = -step[i]; }
+    tr.reuse_diagonal = 1;
+    double mcc = 0.0;
+    if (ok) {
+      double gts = 0.0, shs = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        gts += gs[i] * step[i];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          // Hs[i][j] rebuilt from the packed system exactly as A was formed (before damping)
+          const int p = i < j ? i : j, q = i < j ? j : i;
+          const int idx = 7 + p * 6 - (p * (p - 1)) / 2 + (q - p);
+          shs += step[i] * (tr.sys[idx] * tr.scale[p] * tr.scale[q]) * step[j];
+        }
+      }
+      mcc = -gts - 0.5 * shs;
+    }
+    tr.model_cost_change = mcc;
+    if (!ok || !(mcc > 0.0)) {          // HandleInvalidStep
+      if (++tr.invalid >= prm.max_invalid) return 0;
+      tr.radius *= 0.5;
+      tr.step_ok = 0;
+      continue;
+    }
+    tr.invalid = 0;
+    const pose7 x = load_pose(tr.x);
+    const pose7 cand = pose_plus(x, mk3(step[0] * tr.scale[0], step[1] * tr.scale[1], step[2] * tr.scale[2]),
+                                 mk3(step[3] * tr.scale[3], step[4] * tr.scale[4], step[5] * tr.scale[5]));
+    store_pose(tr.cand, cand);
+    double sn = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) { const double d = tr.x[i] - tr.cand[i]; sn += d * d; }
+    sn = sqrt(sn);
+    if (sn <= prm.ptol * (tr.x_norm + prm.ptol)) return 0;   // ParameterToleranceReached
+    return 1;
+  }
+}
+
+// FunctionToleranceReached / IsStepSuccessful / HandleSuccessfulStep / HandleUnsuccessfulStep,
+// lane 0 only; `red` = {cost, g, H} evaluated at tr.cand.  Returns 1 to continue.
+__device__ __noinline__ int tr_decide(TrState& tr, const double* red, const SolverParams& prm) {
+  const double cand_cost = red[0];
+  const double cost_change = tr.cost - cand_cost;
+  if (fabs(cost_change) <= prm.ftol * tr.cost) return 0;
+  const double rel = cost_change / tr.model_cost_change;
+  if (rel > prm.min_relative_decrease) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) tr.x[i] = tr.cand[i];
+#pragma unroll
+    for (int k = 0; k < kAcc; k++) tr.sys[k] = red[k];
+    const pose7 x = load_pose(tr.x);
+    tr.x_norm = pose_norm(x);
+    tr.cost = cand_cost;
+    tr.gmax = gradient_max_norm(x, tr.sys + 1);
+    const double t = 2.0 * rel - 1.0;
+    tr.radius = fmin(tr.radius / fmax(1.0 / 3.0, 1.0 - t * t * t), prm.radius_max);
+    tr.decrease_factor = 2.0;
+    tr.reuse_diagonal = 0;
+    tr.step_ok = 1;
+    tr.successful++;
+  } else {
+    tr.radius = tr.radius / tr.decrease_factor;
+    tr.decrease_factor *= 2.0;
+    tr.reuse_diagonal = 1;
+    tr.step_ok = 0;
+  }
+  return 1;
 }
 
 // One workgroup per scan, persistent over all trust-region iterations of one ceres::Solve.
-// Thread 0 runs the (serial, tiny) trust-region logic between evaluation passes; every pass
+// Lane 0 runs the (serial, tiny) trust-region logic between evaluation passes; every pass
 // evaluates cost AND the normal equations at the candidate, so an accepted step needs no second
 // pass (Ceres re-evaluates; the values are identical).
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, 3)
 lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const double* __restrict__ rec_all,
                 double* __restrict__ poses, int* __restrict__ status, DevMatchInfo* __restrict__ info,
                 int outer_it, SolverParams prm) {
@@ -536,24 +726,20 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
   const double* rec = rec_all + 6 * r0;
   const double* pprime = pprime_all ? pprime_all + 3 * r0 : nullptr;
   double* pose_g = poses + 7 * (size_t)b;
+  TrState& tr = sh.tr;
 
-  double acc[kAcc];
-  int ne, np;
-  pose7 T = load_pose(pose_g);
-  evaluate_pass<BLOCK>(T, prm.huber, corner, nc, surf, ns, pprime, rec, acc, ne, np);
-  block_reduce<BLOCK>(sh, acc, ne, np);
-
-  // trust-region state, owned by thread 0 (kept in registers of lane 0 only)
-  double H[6][6], g[6], scale[6], diagonal[6];
-  double cost = 0, gmax = 0, x_norm = 0, radius = prm.radius0, decrease_factor = 2.0, model_cost_change = 0;
-  pose7 x = T, cand = T;
-  int iteration = 0, invalid = 0, successful = 0;
-  bool reuse_diagonal = false, step_ok = true;
-
+  {
+    double acc[kAcc];
+    int ne, np;
+    const pose7 T = load_pose(pose_g);
+    evaluate_pass<BLOCK>(T, prm.huber, corner, nc, surf, ns, pprime, rec, acc, ne, np);
+    block_reduce<BLOCK>(sh, acc, ne, np);
+  }
   if (threadIdx.x == 0) {
     const int n_edge = sh.cnt[0], n_plane = sh.cnt[1];
     int go = 1;
     if (info) { info[b].n_edge[outer_it] = n_edge; info[b].n_plane[outer_it] = n_plane; }
+    tr.cost = 0.0; tr.iteration = 0; tr.successful = 0;
     if (n_edge + n_plane < prm.min_correspondences) {
       status[b] = 1;                       // MSFL_TOO_FEW_CORRESPONDENCES (odometry_scan_matcher.cc:262-267)
       if (info) info[b].status = 1;
@@ -561,130 +747,46 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
     } else if (n_edge + n_plane == 0) {
       go = 0;                              // Ceres: empty problem, parameters untouched
     } else {
-      unpack_system(sh.red, H, g);
-      cost = sh.red[0];
-      if (info) info[b].initial_cost[outer_it] = cost;
 #pragma unroll
-      for (int i = 0; i < 6; i++) scale[i] = 1.0 / (1.0 + sqrt(H[i][i]));   // jacobi_scaling, iteration 0
-      gmax = gradient_max_norm(x, g);
-      x_norm = pose_norm(x);
+      for (int k = 0; k < kAcc; k++) tr.sys[k] = sh.red[k];
+#pragma unroll
+      for (int i = 0; i < 7; i++) tr.x[i] = pose_g[i];
+      tr.cost = sh.red[0];
+      if (info) info[b].initial_cost[outer_it] = tr.cost;
+      // jacobi_scaling from iteration 0: 1 / (1 + sqrt(diag(J^T J)))
+      const int dg[6] = {7, 13, 18, 22, 25, 27};   // packed positions of H[i][i]
+#pragma unroll
+      for (int i = 0; i < 6; i++) tr.scale[i] = 1.0 / (1.0 + sqrt(sh.red[dg[i]]));
+      const pose7 x = load_pose(tr.x);
+      tr.gmax = gradient_max_norm(x, tr.sys + 1);
+      tr.x_norm = pose_norm(x);
+      tr.radius = prm.radius0; tr.decrease_factor = 2.0; tr.model_cost_change = 0.0;
+      tr.invalid = 0; tr.reuse_diagonal = 0; tr.step_ok = 1;
+      go = tr_propose(tr, prm);
     }
     sh.go = go;
   }
   __syncthreads();
-  if (!sh.go) {
-    if (threadIdx.x == 0 && info) { info[b].lm_iterations[outer_it] = 0; info[b].lm_successful[outer_it] = 0; info[b].final_cost[outer_it] = cost; }
-    return;
-  }
-
-  for (;;) {
-    if (threadIdx.x == 0) {
-      int go = 0;
-      // FinalizeIterationAndCheckIfMinimizerCanContinue + ComputeTrustRegionStep; loops here
-      // over invalid steps (they need no evaluation pass)
-      for (;;) {
-        if (iteration >= prm.max_iterations) break;
-        if (step_ok && gmax <= prm.gtol) break;
-        if (radius < prm.radius_min) break;
-        iteration++;
-        double Hs[6][6], gs[6], A[6][6], y[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-          gs[i] = g[i] * scale[i];
-#pragma unroll
-          for (int j = 0; j < 6; j++) Hs[i][j] = H[i][j] * scale[i] * scale[j];
-        }
-        if (!reuse_diagonal) {
-#pragma unroll
-          for (int i = 0; i < 6; i++) diagonal[i] = fmin(fmax(Hs[i][i], prm.min_diag), prm.max_diag);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-#pragma unroll
-          for (int j = 0; j < 6; j++) A[i][j] = Hs[i][j];
-          const double lm = sqrt(diagonal[i] / radius);
-          A[i][i] += lm * lm;
-        }
-        const bool ok = chol_solve6(A, gs, y);
-        reuse_diagonal = true;
-        double step[6];
-        model_cost_change = 0.0;
-        if (ok) {
-          double gts = 0.0, shs = 0.0;
-#pragma unroll
-          for (int i = 0; i < 6; i++) step[i] = -y[i];
-#pragma unroll
-          for (int i = 0; i < 6; i++) {
-            gts += gs[i] * step[i];
-#pragma unroll
-            for (int j = 0; j < 6; j++) shs += step[i] * Hs[i][j] * step[j];
-          }
-          model_cost_change = -gts - 0.5 * shs;
-        }
-        if (!ok || !(model_cost_change > 0.0)) {          // HandleInvalidStep
-          if (++invalid >= prm.max_invalid) break;
-          radius *= 0.5;
-          step_ok = false;
-          continue;
-        }
-        invalid = 0;
-        cand = pose_plus(x, mk3(step[0] * scale[0], step[1] * scale[1], step[2] * scale[2]),
-                         mk3(step[3] * scale[3], step[4] * scale[4], step[5] * scale[5]));
-        // ParameterToleranceReached (needs no evaluation)
-        const double dx0 = x.t.x - cand.t.x, dx1 = x.t.y - cand.t.y, dx2 = x.t.z - cand.t.z;
-        const double dx3 = x.q.x - cand.q.x, dx4 = x.q.y - cand.q.y, dx5 = x.q.z - cand.q.z, dx6 = x.q.w - cand.q.w;
-        const double sn = sqrt(dx0 * dx0 + dx1 * dx1 + dx2 * dx2 + dx3 * dx3 + dx4 * dx4 + dx5 * dx5 + dx6 * dx6);
-        if (sn <= prm.ptol * (x_norm + prm.ptol)) break;
-        go = 1;
-        break;
-      }
-      if (go) store_pose(sh.cand, cand);
-      sh.go = go;
-    }
-    __syncthreads();
-    if (!sh.go) break;
-    T = load_pose(sh.cand);
+  bool solved = (sh.cnt[0] + sh.cnt[1] >= prm.min_correspondences) && (sh.cnt[0] + sh.cnt[1] > 0);
+  while (sh.go) {
+    double acc[kAcc];
+    int ne, np;
+    const pose7 T = load_pose(tr.cand);
+    __syncthreads();                       // everyone has read go / cand before lane 0 may overwrite them
     evaluate_pass<BLOCK>(T, prm.huber, corner, nc, surf, ns, pprime, rec, acc, ne, np);
     block_reduce<BLOCK>(sh, acc, ne, np);
-    if (threadIdx.x == 0) {
-      const double cand_cost = sh.red[0];
-      const double cost_change = cost - cand_cost;
-      bool stop = false;
-      if (fabs(cost_change) <= prm.ftol * cost) {           // FunctionToleranceReached
-        stop = true;
-      } else {
-        const double rel = cost_change / model_cost_change;
-        if (rel > prm.min_relative_decrease) {              // HandleSuccessfulStep
-          x = cand;
-          x_norm = pose_norm(x);
-          unpack_system(sh.red, H, g);
-          cost = cand_cost;
-          gmax = gradient_max_norm(x, g);
-          const double t = 2.0 * rel - 1.0;
-          radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
-          radius = fmin(radius, prm.radius_max);
-          decrease_factor = 2.0;
-          reuse_diagonal = false;
-          step_ok = true;
-          successful++;
-        } else {                                            // HandleUnsuccessfulStep
-          radius = radius / decrease_factor;
-          decrease_factor *= 2.0;
-          reuse_diagonal = true;
-          step_ok = false;
-        }
-      }
-      sh.go = stop ? 0 : 1;
-    }
+    if (threadIdx.x == 0) sh.go = tr_decide(tr, sh.red, prm) ? tr_propose(tr, prm) : 0;
     __syncthreads();
-    if (!sh.go) break;
   }
   if (threadIdx.x == 0) {
-    store_pose(pose_g, x);
+    if (solved) {
+#pragma unroll
+      for (int i = 0; i < 7; i++) pose_g[i] = tr.x[i];
+    }
     if (info) {
-      info[b].lm_iterations[outer_it] = iteration;
-      info[b].lm_successful[outer_it] = successful;
-      info[b].final_cost[outer_it] = cost;
+      info[b].lm_iterations[outer_it] = tr.iteration;
+      info[b].lm_successful[outer_it] = tr.successful;
+      info[b].final_cost[outer_it] = tr.cost;
     }
   }
 }
