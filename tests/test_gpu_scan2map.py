@@ -129,3 +129,33 @@ def test_edge_cases(gpu, oracle):
     s, _, _ = h3.match_scan2map(far, far, pose, allow=(capi.NO_MAP,))
     assert s == capi.NO_MAP
     h2.close(); h3.close()
+
+
+def test_deskew_variant_matches_oracle(gpu, oracle):
+    """is_initialized branch (LidarEdge/PlaneFactorDeskewSE3, lidar_factor.cc:46-100) with synthetic
+    per-point (delta_q, delta_p), velocity and gravity."""
+    _, mc, ms = common.small_world()
+    gpu.set_map(mc, ms)
+    rng = np.random.default_rng(21)
+    for pts, ring, truth, guess in common.scans(2):
+        f, corner, surf = common.features_from_oracle(oracle, pts, ring)
+        V = np.array([0.8, -0.3, 0.05]); G = np.array([0.0, 0.0, 9.81])
+        def dqdp(cloud):
+            t = cloud[:, 3].astype(np.float64)
+            rv = np.outer(t, [0.02, -0.01, 0.3])                      # small rotation growing with time
+            dq = np.stack([synth.quat_from_rotvec(r) for r in rv])
+            dp = np.outer(t, [0.05, 0.02, -0.01]) + rng.normal(0, 1e-4, (len(t), 3))
+            return dq, dp
+        cdq, cdp = dqdp(corner); sdq, sdp = dqdp(surf)
+        rc, pose_o, info_o = oracle.match_scan2map_deskew(mc, ms, corner, surf, cdq, cdp, sdq, sdp, V, G, guess)
+        s, pose_g, info_g = gpu.match_scan2map_deskew(corner, surf, cdq, cdp, sdq, sdp, V, G, guess)
+        assert s == 0 and rc == 0
+        assert list(info_g.n_edge) == list(info_o.n_edge) and list(info_g.n_plane) == list(info_o.n_plane)
+        dt, dr = synth.pose_error(pose_g, pose_o)
+        assert dt < TIGHT and dr < TIGHT, (dt, dr)
+        # zero deskew (identity dq, zero dp, V = G = 0) reproduces the plain matcher bit for bit
+        zq = np.tile([0, 0, 0, 1.0], (len(corner), 1)); zs = np.tile([0, 0, 0, 1.0], (len(surf), 1))
+        s, p0, _ = gpu.match_scan2map_deskew(corner, surf, zq, np.zeros((len(corner), 3)), zs, np.zeros((len(surf), 3)),
+                                             np.zeros(3), np.zeros(3), guess)
+        s, p1, _ = gpu.match_scan2map(corner, surf, guess)
+        assert synth.pose_error(p0, p1)[0] < 1e-12

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect rocprofv3 PMC counters for the bench workload in separate passes (gpurun forbids mixing
+# --pmc with tracing domains other than --kernel-trace/--stats).  Run on the GPU box:
+#   bash tools/pmc.sh <tag> [bench args]
+set -u
+TAG=${1:-pmc}; shift || true
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 3 --warmup 1 --cpu-sample 0 $*"
+i=0
+for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" \
+           "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
+           "TCC_HIT_sum TCC_MISS_sum" \
+           "FETCH_SIZE" \
+           "WRITE_SIZE" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT -o pass$i -- python $ROOT/bench.py $ARGS > $OUT/pass$i.log 2>&1
+done
+python $ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
