@@ -1,0 +1,252 @@
+// msfl/scan_matcher.hpp — C++ host-side mirror of MSF_LOAM's scan-matching interface over the
+// C ABI (include/msfl_c_api.h).  Header-only, C++14, no PCL / Eigen / Ceres.
+//
+// Same class names, method names, argument meaning and error behaviour as the reference:
+//   msfl::OdometryScanMatcher::MatchScan2Scan   <- src/slam/local/scan_matching/odometry_scan_matcher.h:10-12
+//   msfl::MappingScanMatcher::MatchScan2Map     <- src/slam/local/scan_matching/mapping_scan_matcher.h:14-21
+//   msfl::ScanRegistration::Extract             <- RealHandleLaserCloudMessage, src/msf_loam_node.cc:160-378
+//   msfl::Rigid3d                               <- src/common/rigid_transform.h:36-128
+//   msfl::TimestampedPointCloud<T>              <- src/common/timestamped_pointcloud.h:11-42
+//   msfl::PointXYZI / PointXYZIRT               <- pcl::PointXYZI / src/common/common.h:44-62
+// The point types here are packed PODs; INTEGRATION.md shows the 10-line conversion from the
+// reference's 32-byte PCL points.  Everything heavy runs in libmsfl_hip.so on the GPU; these
+// classes only marshal.  A matcher object owns one msfl_handle (one HIP stream), exactly as the
+// reference owns one matcher per thread (laser_odometry.h:29, laser_mapping.h:65).
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../msfl_c_api.h"
+
+namespace msfl {
+
+struct PointXYZI { float x, y, z, intensity; };                       // 16 B == msfl_point
+struct PointXYZIRT { float x, y, z, intensity; std::uint16_t ring; float time; };
+using PointType = PointXYZI;                                            // common.h:64
+using PointTypeOriginal = PointXYZIRT;                                  // common.h:69
+
+template <typename T>
+struct PointCloud {
+  std::vector<T> points;
+  std::size_t size() const { return points.size(); }
+  bool empty() const { return points.empty(); }
+  void push_back(const T& p) { points.push_back(p); }
+  T& operator[](std::size_t i) { return points[i]; }
+  const T& operator[](std::size_t i) const { return points[i]; }
+};
+
+using Vector3d = std::array<double, 3>;
+
+// rigid_transform.h:36-128.  rotation stored [x y z w] like Eigen::Quaterniond::coeffs().
+class Rigid3d {
+ public:
+  Rigid3d() : t_{{0, 0, 0}}, q_{{0, 0, 0, 1}} {}
+  Rigid3d(const Vector3d& t, const std::array<double, 4>& q_xyzw) : t_(t), q_(q_xyzw) {}
+  explicit Rigid3d(const std::array<double, 7>& v) : t_{{v[0], v[1], v[2]}}, q_{{v[3], v[4], v[5], v[6]}} {}  // :47-49, no normalisation
+  std::array<double, 7> ToVector7() const { return {{t_[0], t_[1], t_[2], q_[0], q_[1], q_[2], q_[3]}}; }  // :59-64
+  static Rigid3d Identity() { return Rigid3d(); }
+  const Vector3d& translation() const { return t_; }
+  const std::array<double, 4>& rotation() const { return q_; }
+  Vector3d& translation() { return t_; }
+  std::array<double, 4>& rotation() { return q_; }
+  Vector3d operator*(const Vector3d& p) const {                        // :113-118
+    const Vector3d r = Rotate(q_, p);
+    return {{r[0] + t_[0], r[1] + t_[1], r[2] + t_[2]}};
+  }
+  Rigid3d inverse() const {                                            // :79-83
+    const std::array<double, 4> c{{-q_[0], -q_[1], -q_[2], q_[3]}};
+    const Vector3d r = Rotate(c, t_);
+    return Rigid3d({{-r[0], -r[1], -r[2]}}, c);
+  }
+  friend Rigid3d operator*(const Rigid3d& a, const Rigid3d& b) {       // :105-111 (renormalises)
+    const Vector3d r = Rotate(a.q_, b.t_);
+    std::array<double, 4> q{{a.q_[3] * b.q_[0] + a.q_[0] * b.q_[3] + a.q_[1] * b.q_[2] - a.q_[2] * b.q_[1],
+                             a.q_[3] * b.q_[1] + a.q_[1] * b.q_[3] + a.q_[2] * b.q_[0] - a.q_[0] * b.q_[2],
+                             a.q_[3] * b.q_[2] + a.q_[2] * b.q_[3] + a.q_[0] * b.q_[1] - a.q_[1] * b.q_[0],
+                             a.q_[3] * b.q_[3] - a.q_[0] * b.q_[0] - a.q_[1] * b.q_[1] - a.q_[2] * b.q_[2]}};
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (n > 0) for (double& c : q) c /= n;
+    return Rigid3d({{r[0] + a.t_[0], r[1] + a.t_[1], r[2] + a.t_[2]}}, q);
+  }
+
+ private:
+  static Vector3d Rotate(const std::array<double, 4>& q, const Vector3d& v) {   // Eigen _transformVector
+    Vector3d uv{{q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]}};
+    for (double& c : uv) c += c;
+    const Vector3d c{{q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]}};
+    return {{v[0] + q[3] * uv[0] + c[0], v[1] + q[3] * uv[1] + c[1], v[2] + q[3] * uv[2] + c[2]}};
+  }
+  Vector3d t_;
+  std::array<double, 4> q_;
+};
+
+// timestamped_pointcloud.h:11-42
+template <typename T>
+struct TimestampedPointCloud {
+  using PointCloudType = PointCloud<T>;
+  using PointCloudTypePtr = std::shared_ptr<PointCloudType>;
+  double time = 0.0;
+  std::string frame_id;
+  Rigid3d odom_pose, map_pose;
+  PointCloudTypePtr cloud_full_res, cloud_corner_sharp, cloud_corner_less_sharp, cloud_surf_flat, cloud_surf_less_flat;
+  TimestampedPointCloud()
+      : cloud_full_res(new PointCloudType), cloud_corner_sharp(new PointCloudType),
+        cloud_corner_less_sharp(new PointCloudType), cloud_surf_flat(new PointCloudType),
+        cloud_surf_less_flat(new PointCloudType) {}
+};
+
+// Inputs of the is_initialized branch that the reference derives from `preintegration`,
+// `gravity_vector` and `prev_state` (mapping_scan_matcher.cc:112-121): GetDeltaQP(preintegration, dt)
+// per feature point (scan_undistortion.cc:22-42), computed by the caller.
+struct DeskewInputs {
+  std::vector<std::array<double, 4>> corner_delta_q, surf_delta_q;   // [x y z w]
+  std::vector<Vector3d> corner_delta_p, surf_delta_p;
+  Vector3d gravity_vector{{0, 0, 0}};
+};
+
+namespace detail {
+inline void Check(msfl_status s, msfl_handle* h, const char* what) {
+  // the reference aborts through glog CHECK on invariant violations; here: an exception
+  if (s != MSFL_OK) throw std::runtime_error(std::string(what) + ": " + msfl_status_string(s) + " " + (h ? msfl_last_error(h) : ""));
+}
+inline std::vector<msfl_point> Pack(const PointCloud<PointXYZI>& c) {
+  std::vector<msfl_point> o(c.size());
+  for (std::size_t i = 0; i < c.size(); ++i) o[i] = msfl_point{c[i].x, c[i].y, c[i].z, c[i].intensity};
+  return o;
+}
+inline void Pack(const PointCloud<PointXYZIRT>& c, std::vector<msfl_point>* p, std::vector<std::uint16_t>* r) {
+  p->resize(c.size()); r->resize(c.size());
+  for (std::size_t i = 0; i < c.size(); ++i) { (*p)[i] = msfl_point{c[i].x, c[i].y, c[i].z, c[i].intensity}; (*r)[i] = c[i].ring; }
+}
+}  // namespace detail
+
+// scan_matcher.h:13-22.  RefineByRejectOutliersWithThreshold is a no-op in the reference
+// (scan_matcher.cc:13-38, body commented out) and is therefore absent.
+class ScanMatcher {
+ public:
+  explicit ScanMatcher(int device = 0, const msfl_params* params = nullptr) {
+    detail::Check(msfl_create(params, device, &h_), nullptr, "msfl_create");
+  }
+  virtual ~ScanMatcher() { msfl_destroy(h_); }
+  ScanMatcher(const ScanMatcher&) = delete;
+  ScanMatcher& operator=(const ScanMatcher&) = delete;
+  msfl_handle* handle() const { return h_; }
+  const msfl_match_info& last_info() const { return info_; }
+
+ protected:
+  msfl_handle* h_ = nullptr;
+  msfl_match_info info_{};
+};
+
+class OdometryScanMatcher : public ScanMatcher {
+ public:
+  using ScanMatcher::ScanMatcher;
+  // Returns false exactly where the reference does (< 10 correspondences, .cc:262-267); the pose
+  // then holds the outer iterations completed so far.
+  virtual bool MatchScan2Scan(const TimestampedPointCloud<PointTypeOriginal>& scan_last,
+                              const TimestampedPointCloud<PointTypeOriginal>& scan_curr,
+                              Rigid3d* pose_estimate_curr2last) {
+    std::vector<msfl_point> p[4]; std::vector<std::uint16_t> r[4];
+    detail::Pack(*scan_last.cloud_corner_less_sharp, &p[0], &r[0]);
+    detail::Pack(*scan_last.cloud_surf_less_flat, &p[1], &r[1]);
+    detail::Pack(*scan_curr.cloud_corner_sharp, &p[2], &r[2]);
+    detail::Pack(*scan_curr.cloud_surf_flat, &p[3], &r[3]);
+    msfl_ring_cloud c[4];
+    for (int k = 0; k < 4; ++k) c[k] = msfl_ring_cloud{p[k].data(), r[k].data(), static_cast<int>(p[k].size())};
+    auto v = pose_estimate_curr2last->ToVector7();
+    const msfl_status s = msfl_match_scan2scan(h_, &c[0], &c[1], &c[2], &c[3], v.data(), &info_, MSFL_MEM_HOST);
+    if (s != MSFL_OK && s != MSFL_TOO_FEW_CORRESPONDENCES) detail::Check(s, h_, "msfl_match_scan2scan");
+    *pose_estimate_curr2last = Rigid3d(v);
+    return s == MSFL_OK;
+  }
+};
+
+class MappingScanMatcher : public ScanMatcher {
+ public:
+  using ScanMatcher::ScanMatcher;
+  // cloud_map / scan_curr: only cloud_corner_less_sharp and cloud_surf_less_flat are read
+  // (mapping_scan_matcher.cc:71-72,109,179).  `deskew` non-null selects the is_initialized branch
+  // (per-point time comes from PointXYZI::intensity, .cc:114); `velocity` is read as Vi and written
+  // back unchanged (the reference holds the velocity block constant, .cc:94,269).
+  // Always returns true like the reference (.cc:277) unless the map is unusable (MAP_TOO_SMALL:
+  // the caller's gate laser_mapping.cc:284-285 normally prevents that) -> false, pose untouched.
+  bool MatchScan2Map(const TimestampedPointCloud<PointType>& cloud_map,
+                     const TimestampedPointCloud<PointType>& scan_curr,
+                     const bool is_initialized, const DeskewInputs* deskew,
+                     Rigid3d* pose_estimate_map_scan2world, Vector3d* velocity) {
+    const std::vector<msfl_point> mc = detail::Pack(*cloud_map.cloud_corner_less_sharp);
+    const std::vector<msfl_point> ms = detail::Pack(*cloud_map.cloud_surf_less_flat);
+    detail::Check(msfl_set_map(h_, mc.data(), static_cast<int>(mc.size()), ms.data(), static_cast<int>(ms.size()), MSFL_MEM_HOST),
+                  h_, "msfl_set_map");                                   // kd-tree build, .cc:66-73
+    const std::vector<msfl_point> c = detail::Pack(*scan_curr.cloud_corner_less_sharp);
+    const std::vector<msfl_point> s = detail::Pack(*scan_curr.cloud_surf_less_flat);
+    auto v = pose_estimate_map_scan2world->ToVector7();
+    msfl_status st;
+    if (is_initialized) {
+      if (!deskew || !velocity || deskew->corner_delta_q.size() != c.size() || deskew->surf_delta_q.size() != s.size() ||
+          deskew->corner_delta_p.size() != c.size() || deskew->surf_delta_p.size() != s.size())
+        throw std::invalid_argument("MatchScan2Map: is_initialized needs per-point deskew inputs of matching size");
+      msfl_deskew d;
+      d.corner_dq = c.empty() ? nullptr : deskew->corner_delta_q[0].data();
+      d.corner_dp = c.empty() ? nullptr : deskew->corner_delta_p[0].data();
+      d.surf_dq = s.empty() ? nullptr : deskew->surf_delta_q[0].data();
+      d.surf_dp = s.empty() ? nullptr : deskew->surf_delta_p[0].data();
+      for (int a = 0; a < 3; ++a) { d.velocity[a] = (*velocity)[a]; d.gravity[a] = deskew->gravity_vector[a]; }
+      st = msfl_match_scan2map_deskew(h_, c.data(), static_cast<int>(c.size()), s.data(), static_cast<int>(s.size()), &d, v.data(), &info_);
+    } else {
+      st = msfl_match_scan2map(h_, c.data(), static_cast<int>(c.size()), s.data(), static_cast<int>(s.size()), v.data(), &info_, MSFL_MEM_HOST);
+    }
+    if (st == MSFL_MAP_TOO_SMALL) return false;
+    detail::Check(st, h_, "msfl_match_scan2map");
+    *pose_estimate_map_scan2world = Rigid3d(v);
+    return true;
+  }
+};
+
+// RealHandleLaserCloudMessage (msf_loam_node.cc:160-378) between pcl::fromROSMsg and AddLaserScan.
+class ScanRegistration {
+ public:
+  explicit ScanRegistration(int device = 0, double min_range = 0.3, const Rigid3d& lidar2imu = Rigid3d::Identity())
+      : lidar2imu_(lidar2imu) {
+    msfl_params p; msfl_default_params(&p); p.min_range = min_range;
+    detail::Check(msfl_create(&p, device, &h_), nullptr, "msfl_create");
+  }
+  ~ScanRegistration() { msfl_destroy(h_); }
+  ScanRegistration(const ScanRegistration&) = delete;
+  ScanRegistration& operator=(const ScanRegistration&) = delete;
+
+  TimestampedPointCloud<PointTypeOriginal> Extract(const PointCloud<PointTypeOriginal>& laser_cloud_in, double stamp) {
+    std::vector<msfl_point> p; std::vector<std::uint16_t> r;
+    detail::Pack(laser_cloud_in, &p, &r);
+    const std::size_t n = p.size();
+    std::vector<msfl_point> full(n); std::vector<std::uint16_t> ring(n); std::vector<float> curv(n); std::vector<std::uint8_t> label(n);
+    std::vector<int> idx[4];
+    for (auto& v : idx) v.resize(n);
+    msfl_features f{};
+    f.full_pts = full.data(); f.full_ring = ring.data(); f.curvature = curv.data(); f.label = label.data();
+    f.sharp_idx = idx[0].data(); f.less_sharp_idx = idx[1].data(); f.flat_idx = idx[2].data(); f.less_flat_idx = idx[3].data();
+    const auto ext = lidar2imu_.ToVector7();
+    detail::Check(msfl_extract_features(h_, p.data(), r.data(), static_cast<int>(n), ext.data(), &f, MSFL_MEM_HOST), h_,
+                  "msfl_extract_features");
+    TimestampedPointCloud<PointTypeOriginal> scan;
+    scan.time = stamp;
+    auto at = [&](int i) { return PointXYZIRT{full[i].x, full[i].y, full[i].z, full[i].t, ring[i], full[i].t}; };   // time == intensity, :152-153
+    for (int i = 0; i < f.n_full; ++i) scan.cloud_full_res->push_back(at(i));
+    for (int k = 0; k < f.n_sharp; ++k) scan.cloud_corner_sharp->push_back(at(idx[0][k]));
+    for (int k = 0; k < f.n_less_sharp; ++k) scan.cloud_corner_less_sharp->push_back(at(idx[1][k]));
+    for (int k = 0; k < f.n_flat; ++k) scan.cloud_surf_flat->push_back(at(idx[2][k]));
+    for (int k = 0; k < f.n_less_flat; ++k) scan.cloud_surf_less_flat->push_back(at(idx[3][k]));
+    return scan;
+  }
+
+ private:
+  msfl_handle* h_ = nullptr;
+  Rigid3d lidar2imu_;
+};
+
+}  // namespace msfl

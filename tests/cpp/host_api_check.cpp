@@ -1,0 +1,51 @@
+// Exercises the C++ host mirror (include/msfl/scan_matcher.hpp) end to end on the GPU.
+// usage: host_api_check <in.bin> <out.bin>
+//   in : i32 n_scan_pts | pts(n x (4 f32)) | ring(n x u16) | i32 mc | map corner (mc x 4 f32) | i32 ms | map surf | 7 f64 guess
+//   out: 7 f64 map pose | 7 f64 odom pose | i32 odom_ok | i32 n_sharp n_less_sharp n_flat n_less_flat
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "msfl/scan_matcher.hpp"
+
+template <class T>
+static std::vector<T> rd(FILE* f, std::size_t n) { std::vector<T> v(n); if (n && fread(v.data(), sizeof(T), n, f) != n) { perror("read"); exit(2); } return v; }
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 1;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) return 1;
+  const int n = rd<int>(f, 1)[0];
+  auto pts = rd<float>(f, 4 * (std::size_t)n);
+  auto ring = rd<std::uint16_t>(f, n);
+  const int mc = rd<int>(f, 1)[0]; auto mcp = rd<float>(f, 4 * (std::size_t)mc);
+  const int ms = rd<int>(f, 1)[0]; auto msp = rd<float>(f, 4 * (std::size_t)ms);
+  auto guess = rd<double>(f, 7);
+  fclose(f);
+  msfl::PointCloud<msfl::PointXYZIRT> cloud;
+  for (int i = 0; i < n; ++i) cloud.push_back({pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], 0.f, ring[i], 0.f});
+  msfl::ScanRegistration reg(0);
+  auto scan = reg.Extract(cloud, 0.0);
+  // the mapping thread's input: here simply the un-downsampled feature clouds converted to PointXYZI
+  msfl::TimestampedPointCloud<msfl::PointXYZI> map, cur;
+  for (int i = 0; i < mc; ++i) map.cloud_corner_less_sharp->push_back({mcp[4 * i], mcp[4 * i + 1], mcp[4 * i + 2], 0.f});
+  for (int i = 0; i < ms; ++i) map.cloud_surf_less_flat->push_back({msp[4 * i], msp[4 * i + 1], msp[4 * i + 2], 0.f});
+  for (auto& p : scan.cloud_corner_less_sharp->points) cur.cloud_corner_less_sharp->push_back({p.x, p.y, p.z, p.intensity});
+  for (auto& p : scan.cloud_surf_less_flat->points) cur.cloud_surf_less_flat->push_back({p.x, p.y, p.z, p.intensity});
+  msfl::MappingScanMatcher mapper(0);
+  msfl::Rigid3d pose(std::array<double, 7>{{guess[0], guess[1], guess[2], guess[3], guess[4], guess[5], guess[6]}});
+  msfl::Vector3d vel{{0, 0, 0}};
+  const bool ok = mapper.MatchScan2Map(map, cur, false, nullptr, &pose, &vel);
+  // odometry of the scan against itself from a small offset must come back to ~identity
+  msfl::OdometryScanMatcher odo(0);
+  msfl::Rigid3d rel({{0.05, -0.03, 0.01}}, {{0, 0, 0.005, 0.9999875}});
+  const bool odo_ok = odo.MatchScan2Scan(scan, scan, &rel);
+  FILE* o = fopen(argv[2], "wb");
+  auto v = pose.ToVector7(); auto w = rel.ToVector7();
+  fwrite(v.data(), 8, 7, o); fwrite(w.data(), 8, 7, o);
+  const int ints[5] = {odo_ok ? 1 : 0, (int)scan.cloud_corner_sharp->size(), (int)scan.cloud_corner_less_sharp->size(),
+                       (int)scan.cloud_surf_flat->size(), (int)scan.cloud_surf_less_flat->size()};
+  fwrite(ints, 4, 5, o);
+  fclose(o);
+  return ok ? 0 : 3;
+}
