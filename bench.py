@@ -116,7 +116,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world_size > 1:
+    use_dist = "RANK" in os.environ            # launched by torch.distributed.run (also exercises N=1)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
@@ -140,7 +141,7 @@ def main():
     d_guess = torch.from_numpy(inp["guesses"]).to(dev)
     d_poses = torch.empty_like(d_guess)
     d_status = torch.zeros(B, dtype=torch.int32, device=dev)
-    gather = mdist.PoseGather(B, dev) if world_size > 1 else None
+    gather = mdist.PoseGather(B, dev) if use_dist else None
     n_mc, n_ms = len(inp["map_corner"]), len(inp["map_surf"])
     co, so = inp["corner_off"], inp["surf_off"]
 
@@ -153,7 +154,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world_size > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -169,7 +170,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timing = h.get_timing(reset=True)
     h.set_timing(False)
-    if world_size > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -221,9 +222,9 @@ def main():
                                              % (cb["n"], B, cores, cb["n_single"])}
             out["pose_delta_vs_oracle"] = {"max_m": max(dts), "max_rad": max(drs), "n": cb["n"], "tolerance": 1e-4}
         print(json.dumps(out))
-    if world_size > 1:
-        dist.destroy_process_group()
     h.close()
+    if use_dist:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

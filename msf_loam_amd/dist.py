@@ -46,7 +46,7 @@ class PoseGather:
         self.status = torch.empty((self.world, B), dtype=torch.int32, device=device)
 
     def all_gather(self, poses, status):
-        if self.world == 1:
+        if not dist.is_initialized():
             self.poses[0].copy_(poses); self.status[0].copy_(status)
         else:
             dist.all_gather_into_tensor(self.poses.view(-1), poses.reshape(-1))

@@ -1,0 +1,60 @@
+"""GPU parity at the shapes of the other BASELINE.json configs (they are parity cases, not bench
+lines): a 64-beam ~120k-point scan (configs[3]) and a dense 2M-point map (configs[4])."""
+import numpy as np
+import pytest
+
+from msf_loam_amd import synth
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def test_64_beam_120k_point_scan(gpu, oracle):
+    w, mc, ms = common.small_world()
+    pose = synth.random_poses(1, synth.SEED + 64)[0]
+    pts, ring = synth.make_scan(w, pose, synth.SEED + 65, n_beams=64, n_az=1900, elev=(-24.8, 2.0))
+    assert len(pts) > 90000 and ring.max() == 63
+    f, fo = gpu.extract_features(pts, ring), oracle.extract_features(pts, ring)
+    for k in ("sharp", "less_sharp", "flat", "less_flat", "curvature", "label", "ring"):
+        assert np.array_equal(f[k], fo[k]), k
+    corner, surf = gpu.voxel_downsample(f["full"][f["less_sharp"]], 0.2), gpu.voxel_downsample(f["full"][f["less_flat"]], 0.4)
+    assert np.array_equal(corner, oracle.voxel_grid(fo["full"][fo["less_sharp"]], 0.2))
+    assert np.array_equal(surf, oracle.voxel_grid(fo["full"][fo["less_flat"]], 0.4))
+    gpu.set_map(mc, ms)
+    guess = synth.perturb_pose(pose, np.random.default_rng(64))
+    s, pg, ig = gpu.match_scan2map(corner, surf, guess)
+    rc, po, io = oracle.match_scan2map(mc, ms, corner, surf, guess)
+    assert s == rc == 0 and list(ig.n_plane) == list(io.n_plane) and list(ig.n_edge) == list(io.n_edge)
+    dt, dr = synth.pose_error(pg, po)
+    assert dt < 1e-7 and dr < 1e-7
+    assert len(surf) > 8000
+
+
+def test_dense_2m_point_map(gpu, oracle):
+    w = synth.World(ground_half=synth.ground_half_for_target(2_000_000))
+    mc, ms = synth.make_map(w)
+    assert len(mc) + len(ms) > 1_900_000
+    gpu.set_map(mc, ms)
+    poses = synth.random_poses(2, synth.SEED + 2000)
+    rng = np.random.default_rng(2000)
+    tree_c, tree_s = oracle.KdTree(mc), oracle.KdTree(ms)
+    for i in range(2):
+        pts, ring = synth.make_scan(w, poses[i], synth.SEED + 2001 + i)
+        _, corner, surf = common.features_from_oracle(oracle, pts, ring)
+        guess = synth.perturb_pose(poses[i], rng)
+        rec = gpu.associate_scan2map(corner, surf, guess)
+        corr = oracle.associate_scan2map(mc, ms, corner, surf, guess)
+        assert np.array_equal(np.any(rec[:, 3:] != 0, axis=1), corr["kind"] != 0)
+        s, pg, ig = gpu.match_scan2map(corner, surf, guess)
+        rc, po, io = oracle.match_scan2map(mc, ms, corner, surf, guess)
+        dt, dr = synth.pose_error(pg, po)
+        assert s == rc == 0 and dt < 1e-7 and dr < 1e-7
+    # far-away map: grid cell growth keeps the index exact when the bbox is huge
+    far = ms.copy(); far[:1000, 0] += 30000.0; far[1000:2000, 1] -= 25000.0
+    gpu.set_map(mc, far)
+    pts, ring = synth.make_scan(w, poses[0], synth.SEED + 2001)
+    _, corner, surf = common.features_from_oracle(oracle, pts, ring)
+    guess = synth.perturb_pose(poses[0], rng)
+    rec = gpu.associate_scan2map(corner, surf, guess)
+    corr = oracle.associate_scan2map(mc, far, corner, surf, guess)
+    assert np.array_equal(np.any(rec[:, 3:] != 0, axis=1), corr["kind"] != 0)

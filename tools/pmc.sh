@@ -20,4 +20,6 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT -o pass$i -- python $ROOT/bench.py $ARGS > $OUT/pass$i.log 2>&1
 done
 python $ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+du -sh $OUT/* | sort -h | tail -5
+find $OUT -type f ! -name summary.txt ! -name "*.log" -delete
 cat $OUT/summary.txt
