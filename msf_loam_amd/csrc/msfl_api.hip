@@ -243,7 +243,7 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
 
 // one data-association pass = kNN kernel + fit kernel
 void s_launch_assoc(msfl_handle* h, const BatchView& bv, const double* d_poses, const int* d_status, bool deskew,
-                    const DeskewView& dv, int n_rec) {
+                    const DeskewView& dv, int n_rec, double* full = nullptr) {
   hipStream_t st = h->stream;
   int* nn = h->nn.as<int>();
   const dim3 grid(div_up(n_rec, 256)), block(256);
@@ -265,11 +265,11 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv, const double* d_poses, 
     if (deskew)
       hipLaunchKernelGGL(fit_scan2map_kernel<true>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(),
                          h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
-                         h->records.as<double>());
+                         h->records.as<double>(), full);
     else
       hipLaunchKernelGGL(fit_scan2map_kernel<false>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(),
                          h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
-                         h->records.as<double>());
+                         h->records.as<double>(), full);
   }
 }
 
@@ -629,9 +629,10 @@ msfl_status msfl_associate_scan2map(msfl_handle* h, const msfl_point* corner, in
   BatchView bv;
   s = stage_single(h, corner, n_corner, surf, n_surf, pose, bv); if (s) return s;
   DeskewView dv{};
-  s_launch_assoc(h, bv, h->poses.as<double>(), h->status.as<int>(), false, dv, n);
+  HIPCHK(h, h->pprime.reserve((size_t)n * 6 * sizeof(double)));   // {C,N} staging for the host-format output
+  s_launch_assoc(h, bv, h->poses.as<double>(), h->status.as<int>(), false, dv, n, h->pprime.as<double>());
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipMemcpyAsync(records_out, h->records.p, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(records_out, h->pprime.p, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MSFL_OK;
 }
@@ -644,7 +645,12 @@ msfl_status msfl_solve_records(msfl_handle* h, const msfl_point* corner, int n_c
   const int n = n_corner + n_surf;
   BatchView bv;
   s = stage_single(h, corner, n_corner, surf, n_surf, pose_io, bv); if (s) return s;
-  if (n) HIPCHK(h, hipMemcpyAsync(h->records.p, records, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (n) {
+    HIPCHK(h, h->pprime.reserve((size_t)n * 6 * sizeof(double)));
+    HIPCHK(h, hipMemcpyAsync(h->pprime.p, records, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(pack_records_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, bv, (const double*)h->pprime.as<double>(),
+                       h->records.as<double>());
+  }
   DevMatchInfo* d_info = nullptr;
   if (info) {
     HIPCHK(h, h->info.reserve(sizeof(DevMatchInfo)));

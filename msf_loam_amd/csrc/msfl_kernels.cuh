@@ -8,7 +8,9 @@
 //   features     float4 {x,y,z,t} per point, scans concatenated, B+1 prefix offsets
 //   map (sorted) float4 {x,y,z, bits(original index)} ordered by grid cell (x fastest)
 //   cell_start   int[n_cells+1]
-//   records      6 doubles {C, N} per feature (48 B); N == 0 marks a rejected correspondence
+//   records      per scan: n_corner edge records {C[3], N[3]} (48 B) followed by n_surf plane records
+//                {N[3], N.C} (32 B); N == 0 marks a rejected correspondence.  Scan b starts at
+//                6*(corner_off[b]-corner_off[0]) + 4*(surf_off[b]-surf_off[0]) doubles.
 //   poses        7 doubles per scan
 #pragma once
 #include <hip/hip_runtime.h>
@@ -272,6 +274,11 @@ __device__ __forceinline__ int find_scan(const int* __restrict__ rec_off, int n_
   return lo;
 }
 
+// start (in doubles) of scan b's records: edges 6 doubles each, then planes 4 doubles each
+__device__ __forceinline__ size_t rec_base(const BatchView& bv, int b) {
+  return 6 * (size_t)(bv.corner_off[b] - bv.corner_off[0]) + 4 * (size_t)(bv.surf_off[b] - bv.surf_off[0]);
+}
+
 struct DeskewView {
   // all null for the plain (LiDAR-only) branch
   const double* corner_dq; const double* corner_dp;
@@ -329,23 +336,24 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   }
 }
 
-// K4b: 5 neighbours -> line fit (3x3 Jacobi eigen) / plane fit (5x3 Householder QR) -> {C, N} record
+// K4b: 5 neighbours -> line fit (3x3 Jacobi eigen) / plane fit (5x3 Householder QR) -> record.
+// Edge: {C, N}.  Plane: {N, N.C} (the residual N.(Rp+t-C) only needs the offset N.C).
+// `full` (optional, debug/parity API) receives {C, N} for every feature.
 template <bool DESKEW>
 __global__ void __launch_bounds__(256)
 fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
                     const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
-                    double* __restrict__ rec) {
+                    double* __restrict__ rec, double* __restrict__ full) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bv.n_records) return;
-  double* out = rec + 6 * (size_t)g;
   const int* in = nn + 5 * (size_t)g;
+  const int b = find_scan(bv.rec_off, bv.n_scans, g);
+  const int local = g - bv.rec_off[b];
+  const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
+  const bool is_edge = local < nc;
   FitOut fo; fo.ok = false; fo.C = mk3(0, 0, 0); fo.N = mk3(0, 0, 0);
   const int p0 = in[0];
   if (p0 >= 0) {
-    const int b = find_scan(bv.rec_off, bv.n_scans, g);
-    const int local = g - bv.rec_off[b];
-    const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
-    const bool is_edge = local < nc;
     const float4* mp = is_edge ? map_c : map_s;
     const float4 nb[5] = {mp[p0], mp[in[1]], mp[in[2]], mp[in[3]], mp[in[4]]};
     fo = is_edge ? edge_fit(nb, line_ratio) : plane_fit(nb, plane_tol);
@@ -357,8 +365,38 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
                         dv.V[2] * dt - 0.5 * dv.G[2] * dt * dt);
     }
   }
-  out[0] = fo.C.x; out[1] = fo.C.y; out[2] = fo.C.z;
-  out[3] = fo.N.x; out[4] = fo.N.y; out[5] = fo.N.z;
+  const size_t base = rec_base(bv, b);
+  if (is_edge) {
+    double* out = rec + base + 6 * (size_t)local;
+    out[0] = fo.C.x; out[1] = fo.C.y; out[2] = fo.C.z;
+    out[3] = fo.N.x; out[4] = fo.N.y; out[5] = fo.N.z;
+  } else {
+    double* out = rec + base + 6 * (size_t)nc + 4 * (size_t)(local - nc);
+    out[0] = fo.N.x; out[1] = fo.N.y; out[2] = fo.N.z; out[3] = dot(fo.N, fo.C);
+  }
+  if (full) {
+    double* o = full + 6 * (size_t)g;
+    o[0] = fo.C.x; o[1] = fo.C.y; o[2] = fo.C.z; o[3] = fo.N.x; o[4] = fo.N.y; o[5] = fo.N.z;
+  }
+}
+
+// {C, N} x n_records (host/debug format) -> compact internal records
+__global__ void __launch_bounds__(256) pack_records_kernel(BatchView bv, const double* __restrict__ full, double* __restrict__ rec) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= bv.n_records) return;
+  const int b = find_scan(bv.rec_off, bv.n_scans, g);
+  const int local = g - bv.rec_off[b];
+  const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
+  const double* in = full + 6 * (size_t)g;
+  const size_t base = rec_base(bv, b);
+  if (local < nc) {
+    double* out = rec + base + 6 * (size_t)local;
+#pragma unroll
+    for (int k = 0; k < 6; k++) out[k] = in[k];
+  } else {
+    double* out = rec + base + 6 * (size_t)nc + 4 * (size_t)(local - nc);
+    out[0] = in[3]; out[1] = in[4]; out[2] = in[5]; out[3] = in[3] * in[0] + in[4] * in[1] + in[5] * in[2];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -427,38 +465,41 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
   n_edge = 0; n_plane = 0;
   const mat3 R = quat_to_matrix(T.q);
-  const int n = nc + ns;
-  for (int i = threadIdx.x; i < n; i += BLOCK) {
+  // edges: {C, N}, r = N x (R p + t - C)                                       lidar_factor.cc:12
+  for (int i = threadIdx.x; i < nc; i += BLOCK) {
     const double* r6 = rec + 6 * (size_t)i;
     const d3 C = mk3(r6[0], r6[1], r6[2]);
     const d3 N = mk3(r6[3], r6[4], r6[5]);
     if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) continue;      // rejected correspondence
-    const bool is_edge = i < nc;
     d3 p;
-    if (pprime) {
-      p = mk3(pprime[3 * (size_t)i], pprime[3 * (size_t)i + 1], pprime[3 * (size_t)i + 2]);
-    } else {
-      const float4 f = is_edge ? corner[i] : surf[i - nc];
-      p = mk3((double)f.x, (double)f.y, (double)f.z);          // curr_point: untransformed (:146, :221)
-    }
+    if (pprime) p = mk3(pprime[3 * (size_t)i], pprime[3 * (size_t)i + 1], pprime[3 * (size_t)i + 2]);
+    else { const float4 f = corner[i]; p = mk3((double)f.x, (double)f.y, (double)f.z); }   // curr_point: untransformed (:146)
     const d3 d = quat_rotate(T.q, p) + T.t - C;
-    if (is_edge) {
-      n_edge++;
-      const d3 r = cross(N, d);                                // lidar_factor.cc:12
-      const double s = r.x * r.x + r.y * r.y + r.z * r.z;
-      double rho0, rho1; huber_rho(huber, s, rho0, rho1);
-      acc[0] += 0.5 * rho0;
-      const double sc = sqrt(rho1);
-      acc_row(acc, R, p, mk3(0.0, -N.z, N.y), r.x, sc);        // rows of skew(N), :18-19
-      acc_row(acc, R, p, mk3(N.z, 0.0, -N.x), r.y, sc);
-      acc_row(acc, R, p, mk3(-N.y, N.x, 0.0), r.z, sc);
-    } else {
-      n_plane++;
-      const double r = dot(N, d);                              // lidar_factor.cc:32
-      double rho0, rho1; huber_rho(huber, r * r, rho0, rho1);
-      acc[0] += 0.5 * rho0;
-      acc_row(acc, R, p, N, r, sqrt(rho1));                    // :38-39
-    }
+    n_edge++;
+    const d3 r = cross(N, d);
+    const double s = r.x * r.x + r.y * r.y + r.z * r.z;
+    double rho0, rho1; huber_rho(huber, s, rho0, rho1);
+    acc[0] += 0.5 * rho0;
+    const double sc = sqrt(rho1);
+    acc_row(acc, R, p, mk3(0.0, -N.z, N.y), r.x, sc);          // rows of skew(N), :18-19
+    acc_row(acc, R, p, mk3(N.z, 0.0, -N.x), r.y, sc);
+    acc_row(acc, R, p, mk3(-N.y, N.x, 0.0), r.z, sc);
+  }
+  // planes: {N, N.C}, r = N.(R p + t) - N.C                                    lidar_factor.cc:32
+  const double* recp = rec + 6 * (size_t)nc;
+  for (int i = threadIdx.x; i < ns; i += BLOCK) {
+    const double* r4 = recp + 4 * (size_t)i;
+    const d3 N = mk3(r4[0], r4[1], r4[2]);
+    const double d0 = r4[3];
+    if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) continue;
+    d3 p;
+    if (pprime) { const size_t k = (size_t)(nc + i); p = mk3(pprime[3 * k], pprime[3 * k + 1], pprime[3 * k + 2]); }
+    else { const float4 f = surf[i]; p = mk3((double)f.x, (double)f.y, (double)f.z); }     // :221
+    n_plane++;
+    const double r = dot(N, quat_rotate(T.q, p) + T.t) - d0;
+    double rho0, rho1; huber_rho(huber, r * r, rho0, rho1);
+    acc[0] += 0.5 * rho0;
+    acc_row(acc, R, p, N, r, sqrt(rho1));                      // :38-39
   }
 }
 
@@ -723,7 +764,7 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
   const float4* corner = bv.corner + bv.corner_off[b];
   const float4* surf = bv.surf + bv.surf_off[b];
   const size_t r0 = (size_t)bv.rec_off[b];
-  const double* rec = rec_all + 6 * r0;
+  const double* rec = rec_all + rec_base(bv, b);
   const double* pprime = pprime_all ? pprime_all + 3 * r0 : nullptr;
   double* pose_g = poses + 7 * (size_t)b;
   TrState& tr = sh.tr;

@@ -48,12 +48,11 @@ assoc_scan2scan_kernel(BatchView bv, OdomView ov, const double* __restrict__ pos
   if (q0 >= nq) return;
   const int qi = q0 + threadIdx.x;
   const bool has_q = qi < nq;
-  double* out = rec + 6 * ((size_t)bv.rec_off[b] + qi);
+  // compact records: sharp (edge) features 6 doubles {C,N}, flat (plane) features 4 doubles {N, N.C}
+  double* out = rec + rec_base(bv, b) + (qi < n_sharp ? 6 * (size_t)qi : 6 * (size_t)n_sharp + 4 * (size_t)(qi - n_sharp));
+  const int out_len = qi < n_sharp ? 6 : 4;
   if (status[b] != 0) {
-    if (has_q) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) out[k] = 0.0;
-    }
+    if (has_q) for (int k = 0; k < out_len; k++) out[k] = 0.0;
     return;
   }
   const bool is_edge = has_q && qi < n_sharp;
@@ -171,10 +170,10 @@ assoc_scan2scan_kernel(BatchView bv, OdomView ov, const double* __restrict__ pos
           C = mk3((A.x + Bp.x + Cp.x) / 3, (A.y + Bp.y + Cp.y) / 3, (A.z + Bp.z + Cp.z) / 3);
         }
       }
-      out[0] = C.x; out[1] = C.y; out[2] = C.z; out[3] = N.x; out[4] = N.y; out[5] = N.z;
+      if (edge_pass) { out[0] = C.x; out[1] = C.y; out[2] = C.z; out[3] = N.x; out[4] = N.y; out[5] = N.z; }
+      else { out[0] = N.x; out[1] = N.y; out[2] = N.z; out[3] = dot(N, C); }
     } else if (mine) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) out[k] = 0.0;
+      for (int k = 0; k < out_len; k++) out[k] = 0.0;
     }
   }
 }
