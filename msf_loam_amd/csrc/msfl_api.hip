@@ -78,6 +78,7 @@ struct PinRing {
 struct MapIndex {
   GridDesc g{};
   DevBuf sorted;      // float4[n]
+  DevBuf pos_of;      // int[n]: original index -> position in `sorted`
   DevBuf cell_start;  // int[n_cells + 1]
   int n_input = 0;    // points handed to msfl_set_map
 };
@@ -220,6 +221,7 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   HIPCHK(h, h->idx_count.reserve(((size_t)g.n_cells + 1) * sizeof(int)));
   HIPCHK(h, mi.cell_start.reserve(((size_t)g.n_cells + 1) * sizeof(int)));
   HIPCHK(h, mi.sorted.reserve((size_t)n * sizeof(float4)));
+  HIPCHK(h, mi.pos_of.reserve((size_t)n * sizeof(int)));
   HIPCHK(h, hipMemsetAsync(h->idx_count.p, 0, ((size_t)g.n_cells + 1) * sizeof(int), st));
   hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, g, h->idx_cell_of.as<int>(),
                      h->idx_count.as<int>());
@@ -230,7 +232,7 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(h->idx_cub.p, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(),
                                              g.n_cells + 1, st));
   hipLaunchKernelGGL(grid_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, h->idx_cell_of.as<int>(),
-                     mi.cell_start.as<int>(), h->idx_count.as<int>(), mi.sorted.as<float4>());
+                     mi.cell_start.as<int>(), h->idx_count.as<int>(), mi.sorted.as<float4>(), mi.pos_of.as<int>());
   HIPCHK(h, hipGetLastError());
   // number of indexed (finite) points = cell_start[n_cells]; only needed for the < 5 gate
   int total = 0;
@@ -263,12 +265,12 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv, const double* d_poses, 
   {
     ScopedTimer timer(h, T_FIT);
     if (deskew)
-      hipLaunchKernelGGL(fit_scan2map_kernel<true>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(),
-                         h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
+      hipLaunchKernelGGL(fit_scan2map_kernel<true>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(), h->map_c.pos_of.as<int>(),
+                         h->map_s.sorted.as<float4>(), h->map_s.pos_of.as<int>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
                          h->records.as<double>(), full);
     else
-      hipLaunchKernelGGL(fit_scan2map_kernel<false>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(),
-                         h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
+      hipLaunchKernelGGL(fit_scan2map_kernel<false>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(), h->map_c.pos_of.as<int>(),
+                         h->map_s.sorted.as<float4>(), h->map_s.pos_of.as<int>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
                          h->records.as<double>(), full);
   }
 }
@@ -405,7 +407,7 @@ void msfl_destroy(msfl_handle* h) {
   collect_timing(h);
   for (auto e : h->free_events) (void)hipEventDestroy(e);
   h->pin.release();
-  DevBuf* bufs[] = {&h->map_c.sorted, &h->map_c.cell_start, &h->map_s.sorted, &h->map_s.cell_start, &h->in_corner,
+  DevBuf* bufs[] = {&h->map_c.sorted, &h->map_c.cell_start, &h->map_s.sorted, &h->map_s.cell_start, &h->map_c.pos_of, &h->map_s.pos_of, &h->in_corner,
                     &h->in_surf, &h->in_off, &h->poses, &h->status, &h->info, &h->records, &h->pprime, &h->nn,
                     &h->idx_cell_of, &h->idx_count, &h->idx_bbox, &h->idx_cub, &h->idx_stage};
   for (auto* b : bufs) b->release();

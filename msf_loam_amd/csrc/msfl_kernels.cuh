@@ -104,45 +104,41 @@ __global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restric
 __global__ void __launch_bounds__(256) grid_scatter_kernel(const float4* __restrict__ pts, int n,
                                                             const int* __restrict__ cell_of,
                                                             const int* __restrict__ cell_start, int* __restrict__ cursor,
-                                                            float4* __restrict__ sorted) {
+                                                            float4* __restrict__ sorted, int* __restrict__ pos_of) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = cell_of[i];
-  if (c < 0) return;
+  if (c < 0) { pos_of[i] = -1; return; }
   const int k = atomicSub(&cursor[c], 1) - 1;
   float4 p = pts[i];
   p.w = __int_as_float(i);
   sorted[cell_start[c] + k] = p;
+  pos_of[i] = cell_start[c] + k;      // original index -> position (the fit kernel fetches by index)
 }
 
 // ---------------------------------------------------------------------------------------------
 // K4: association = transform + exact 5-NN + line / plane fit -> {C, N} record
 // ---------------------------------------------------------------------------------------------
 
+// Running 5 best as packed 64-bit keys (f32 distance bits << 32 | original map index): distances
+// are >= 0 so the bit pattern is monotone, and one unsigned compare realises the total order
+// (distance, index).  Branch-free sorted insertion: 5 compares + 10 selects on register pairs.
 struct Top5 {
-  float d0, d1, d2, d3, d4;
-  int i0, i1, i2, i3, i4;     // original map index (tie-break key)
-  int p0, p1, p2, p3, p4;     // position in the sorted map array
+  unsigned long long k0, k1, k2, k3, k4;
 };
 
-__device__ __forceinline__ bool knn_less(float da, int ia, float db, int ib) {
-  return da < db || (da == db && ia < ib);
-}
+__device__ __forceinline__ void top5_init(Top5& t) { t.k0 = t.k1 = t.k2 = t.k3 = t.k4 = ~0ull; }
+__device__ __forceinline__ float top5_d4(const Top5& t) { return __uint_as_float((unsigned int)(t.k4 >> 32)); }  // NaN while < 5 found
 
-#define MSFL_CSWAP(DA, IA, PA, DB, IB, PB)                        \
-  if (knn_less(DB, IB, DA, IA)) {                                 \
-    const float td = DA; DA = DB; DB = td;                        \
-    const int ti = IA; IA = IB; IB = ti;                          \
-    const int tp = PA; PA = PB; PB = tp;                          \
-  }
-
-__device__ __forceinline__ void top5_insert(Top5& t, float d, int idx, int pos) {
-  if (!knn_less(d, idx, t.d4, t.i4)) return;
-  t.d4 = d; t.i4 = idx; t.p4 = pos;
-  MSFL_CSWAP(t.d3, t.i3, t.p3, t.d4, t.i4, t.p4)
-  MSFL_CSWAP(t.d2, t.i2, t.p2, t.d3, t.i3, t.p3)
-  MSFL_CSWAP(t.d1, t.i1, t.p1, t.d2, t.i2, t.p2)
-  MSFL_CSWAP(t.d0, t.i0, t.p0, t.d1, t.i1, t.p1)
+__device__ __forceinline__ void top5_insert(Top5& t, float d, int idx) {
+  const unsigned long long x = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)idx;
+  if (!(x < t.k4)) return;
+  const bool c3 = x < t.k3, c2 = x < t.k2, c1 = x < t.k1, c0 = x < t.k0;
+  t.k4 = c3 ? t.k3 : x;
+  t.k3 = c3 ? (c2 ? t.k2 : x) : t.k3;
+  t.k2 = c2 ? (c1 ? t.k1 : x) : t.k2;
+  t.k1 = c1 ? (c0 ? t.k0 : x) : t.k1;
+  t.k0 = c0 ? x : t.k0;
 }
 
 // flann::L2_Simple<float>: ((dx*dx) + dy*dy) + dz*dz, every operation rounded to f32
@@ -166,9 +162,7 @@ __device__ __forceinline__ float axis_gap(float u, int c) {
 
 __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __restrict__ sorted,
                                           const int* __restrict__ cell_start, float3 q, Top5& t) {
-  t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = INFINITY;
-  t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0x7fffffff;
-  t.p0 = t.p1 = t.p2 = t.p3 = t.p4 = -1;
+  top5_init(t);
   const float ux = (q.x - g.ox) * g.inv_cell, uy = (q.y - g.oy) * g.inv_cell, uz = (q.z - g.oz) * g.inv_cell;
   const int cx = grid_coord(q.x, g.ox, g.inv_cell, g.dx);
   const int cy = grid_coord(q.y, g.oy, g.inv_cell, g.dy);
@@ -186,21 +180,22 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
     if (y < 0 || y >= g.dy || z < 0 || z >= g.dz) continue;
     const float gy = axis_gap(uy, y), gz = axis_gap(uz, z);
     const float row2 = (gy * gy + gz * gz) * cell2;
-    if (row2 > t.d4) continue;
+    if (row2 > top5_d4(t)) continue;          // NaN (fewer than 5 found so far) never prunes
     // trim the x range: drop an end cell whose lower bound exceeds the 5th-best distance
     int a = xs, b = xe;
-    { const float gx = axis_gap(ux, a); if (a < b && row2 + gx * gx * cell2 > t.d4) a++; }
-    { const float gx = axis_gap(ux, b); if (a < b && row2 + gx * gx * cell2 > t.d4) b--; }
+    const float d4 = top5_d4(t);
+    { const float gx = axis_gap(ux, a); if (a < b && row2 + gx * gx * cell2 > d4) a++; }
+    { const float gx = axis_gap(ux, b); if (a < b && row2 + gx * gx * cell2 > d4) b--; }
     const int row = (z * g.dy + y) * g.dx;
     // x-adjacent cells are contiguous in the sorted array: one range per (y, z)
     const int s = cell_start[row + a], e = cell_start[row + b + 1];
     int k = s;
     for (; k + 1 < e; k += 2) {            // two loads in flight
       const float4 m0 = sorted[k], m1 = sorted[k + 1];
-      top5_insert(t, l2_simple(m0, q), __float_as_int(m0.w), k);
-      top5_insert(t, l2_simple(m1, q), __float_as_int(m1.w), k + 1);
+      top5_insert(t, l2_simple(m0, q), __float_as_int(m0.w));
+      top5_insert(t, l2_simple(m1, q), __float_as_int(m1.w));
     }
-    if (k < e) { const float4 m = sorted[k]; top5_insert(t, l2_simple(m, q), __float_as_int(m.w), k); }
+    if (k < e) { const float4 m = sorted[k]; top5_insert(t, l2_simple(m, q), __float_as_int(m.w)); }
   }
 }
 
@@ -288,7 +283,7 @@ struct DeskewView {
 };
 
 // K4a: transform + exact 5-NN.  Low register count (no f64 fits here) -> 8 waves/SIMD to hide the
-// latency of the scattered 16-byte candidate loads.  nn[5*g..] = positions in the sorted map array,
+// latency of the scattered 16-byte candidate loads.  nn[5*g..] = original map indices (nearest first),
 // nn[5*g] = -1 when the feature is rejected by the `pointSearchSqDis[4] < 1.0` gate (:128 / :198).
 template <bool DESKEW>
 __global__ void __launch_bounds__(256)
@@ -329,8 +324,9 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   }
   Top5 t;
   if (is_edge) knn5_grid(gc, map_c, cs_c, q, t); else knn5_grid(gs, map_s, cs_s, q, t);
-  if (t.p4 >= 0 && (double)t.d4 < (double)max_sq_dist) {                // :128 / :198
-    out[0] = t.p0; out[1] = t.p1; out[2] = t.p2; out[3] = t.p3; out[4] = t.p4;
+  if (t.k4 != ~0ull && (double)top5_d4(t) < (double)max_sq_dist) {      // :128 / :198
+    out[0] = (int)(unsigned int)t.k0; out[1] = (int)(unsigned int)t.k1; out[2] = (int)(unsigned int)t.k2;
+    out[3] = (int)(unsigned int)t.k3; out[4] = (int)(unsigned int)t.k4;   // original map indices, nearest first
   } else {
     out[0] = -1;
   }
@@ -341,8 +337,8 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
 // `full` (optional, debug/parity API) receives {C, N} for every feature.
 template <bool DESKEW>
 __global__ void __launch_bounds__(256)
-fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
-                    const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
+fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const int* __restrict__ pos_c,
+                    const float4* __restrict__ map_s, const int* __restrict__ pos_s, const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
                     double* __restrict__ rec, double* __restrict__ full) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bv.n_records) return;
@@ -355,7 +351,8 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
   const int p0 = in[0];
   if (p0 >= 0) {
     const float4* mp = is_edge ? map_c : map_s;
-    const float4 nb[5] = {mp[p0], mp[in[1]], mp[in[2]], mp[in[3]], mp[in[4]]};
+    const int* po = is_edge ? pos_c : pos_s;
+    const float4 nb[5] = {mp[po[p0]], mp[po[in[1]]], mp[po[in[2]]], mp[po[in[3]]], mp[po[in[4]]]};
     fo = is_edge ? edge_fit(nb, line_ratio) : plane_fit(nb, plane_tol);
     if (DESKEW && fo.ok) {
       // C' = C - (Vi dt - G dt^2/2): the velocity block is constant (mapping_scan_matcher.cc:94)
