@@ -178,4 +178,122 @@ assoc_scan2scan_kernel(BatchView bv, OdomView ov, const double* __restrict__ pos
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Latency variant for small batches (the reference's own use: ONE scan pair per call).  With a few
+// hundred queries the tiled kernel above has only 1-3 workgroups per pair and takes ~13 ms; here one
+// WAVEFRONT owns one query and its 64 lanes sweep the previous scan's cloud cooperatively
+// (coalesced 16-byte loads, wave reductions), ~0.1 ms per pair.  Same semantics, three sweeps:
+// exact 1-NN; the two `break` boundaries; the windowed minima with the reference's tie order.
+// ---------------------------------------------------------------------------------------------
+struct DJ { float d; int j; };
+// lexicographic min over (d, j): smallest distance, ties -> smallest j
+__device__ __forceinline__ DJ wave_min_lo(DJ v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float d = __shfl_xor(v.d, o); const int j = __shfl_xor(v.j, o);
+    if (d < v.d || (d == v.d && j < v.j)) { v.d = d; v.j = j; }
+  }
+  return v;
+}
+// smallest distance, ties -> LARGEST j (the descending backward scan meets it first); j = -1 means none
+__device__ __forceinline__ DJ wave_min_hi(DJ v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float d = __shfl_xor(v.d, o); const int j = __shfl_xor(v.j, o);
+    if (j >= 0 && (v.j < 0 || d < v.d || (d == v.d && j > v.j))) { v.d = d; v.j = j; }
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+assoc_scan2scan_wave_kernel(BatchView bv, OdomView ov, const double* __restrict__ poses, const int* __restrict__ status,
+                            double* __restrict__ rec) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int n_sharp = bv.corner_off[b + 1] - bv.corner_off[b];
+  const int n_flat = bv.surf_off[b + 1] - bv.surf_off[b];
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= n_sharp + n_flat) return;
+  const bool edge = qi < n_sharp;
+  double* out = rec + rec_base(bv, b) + (edge ? 6 * (size_t)qi : 6 * (size_t)n_sharp + 4 * (size_t)(qi - n_sharp));
+  const int out_len = edge ? 6 : 4;
+  const float4* tp = edge ? ov.last_ls + ov.last_ls_off[b] : ov.last_lf + ov.last_lf_off[b];
+  const uint16_t* tr = edge ? ov.last_ls_ring + ov.last_ls_off[b] : ov.last_lf_ring + ov.last_lf_off[b];
+  const int nt = edge ? ov.last_ls_off[b + 1] - ov.last_ls_off[b] : ov.last_lf_off[b + 1] - ov.last_lf_off[b];
+  const float thr = (float)ov.dist_sq_threshold;
+  bool ok = status[b] == 0 && nt > 0;
+  float3 q = make_float3(0, 0, 0);
+  int closest = -1;
+  if (ok) {
+    const float4 f = edge ? bv.corner[bv.corner_off[b] + qi] : bv.surf[bv.surf_off[b] + (qi - n_sharp)];
+    q = transform_point_f32(load_pose(poses + 7 * b), f.x, f.y, f.z);
+    DJ best{INFINITY, 0x7fffffff};
+    for (int j = lane; j < nt; j += 64) {                     // sweep 1: exact 1-NN (:84 / :169)
+      const float d = odom_dist(tp[j], q);
+      if (d < best.d) { best.d = d; best.j = j; }
+    }
+    best = wave_min_lo(best);
+    ok = best.j != 0x7fffffff && best.d < thr;               // :87 / :173
+    closest = best.j;
+  }
+  if (!ok) {
+    if (lane < out_len) out[lane] = 0.0;
+    return;
+  }
+  const int id = tr[closest];
+  const float hi_ring = (float)id + (float)ov.nearby_scan, lo_ring = (float)id - (float)ov.nearby_scan;
+  int fwd_end = nt, back_end = -1;                            // sweep 2: first out-of-window ring on each side
+  for (int j = lane; j < nt; j += 64) {
+    const float rj = (float)tr[j];
+    if (j > closest && rj > hi_ring) fwd_end = min(fwd_end, j);
+    if (j < closest && rj < lo_ring) back_end = max(back_end, j);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { fwd_end = min(fwd_end, __shfl_xor(fwd_end, o)); back_end = max(back_end, __shfl_xor(back_end, o)); }
+  DJ f2{thr, 0x7fffffff}, f3{thr, 0x7fffffff}, b2{thr, -1}, b3{thr, -1};
+  for (int j = lane; j < nt; j += 64) {                       // sweep 3: windowed minima
+    if (j == closest || j >= fwd_end || j <= back_end) continue;
+    const int rj = tr[j];
+    if (j > closest) {
+      if (edge) { if (rj <= id) continue; const float d = odom_dist(tp[j], q); if (d < f2.d) { f2.d = d; f2.j = j; } }
+      else {
+        const float d = odom_dist(tp[j], q);
+        if (rj <= id) { if (d < f2.d) { f2.d = d; f2.j = j; } } else { if (d < f3.d) { f3.d = d; f3.j = j; } }
+      }
+    } else {
+      if (edge) { if (rj >= id) continue; const float d = odom_dist(tp[j], q); if (d < b2.d || (d == b2.d && b2.j >= 0)) { b2.d = d; b2.j = j; } }
+      else {
+        const float d = odom_dist(tp[j], q);
+        if (rj >= id) { if (d < b2.d || (d == b2.d && b2.j >= 0)) { b2.d = d; b2.j = j; } }
+        else { if (d < b3.d || (d == b3.d && b3.j >= 0)) { b3.d = d; b3.j = j; } }
+      }
+    }
+  }
+  f2 = wave_min_lo(f2); f3 = wave_min_lo(f3); b2 = wave_min_hi(b2); b3 = wave_min_hi(b3);
+  if (f2.j == 0x7fffffff) f2.j = -1;
+  if (f3.j == 0x7fffffff) f3.j = -1;
+  // the backward scan continues the forward scan's running minimum with strict '<'
+  const int min2 = (b2.j >= 0 && b2.d < f2.d) ? b2.j : f2.j;
+  const int min3 = (b3.j >= 0 && b3.d < f3.d) ? b3.j : f3.j;
+  if (lane != 0) return;
+  d3 C = mk3(0, 0, 0), N = mk3(0, 0, 0);
+  if (edge) {
+    if (min2 >= 0) {
+      const float4 a = tp[closest], c = tp[min2];
+      const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z);
+      N = normalized(A - Bp); C = A;
+    }
+    out[0] = C.x; out[1] = C.y; out[2] = C.z; out[3] = N.x; out[4] = N.y; out[5] = N.z;
+  } else {
+    if (min2 >= 0 && min3 >= 0) {
+      const float4 a = tp[closest], c = tp[min2], e = tp[min3];
+      const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z),
+               Cp = mk3((double)e.x, (double)e.y, (double)e.z);
+      N = normalized(cross(A - Bp, A - Cp));
+      C = mk3((A.x + Bp.x + Cp.x) / 3, (A.y + Bp.y + Cp.y) / 3, (A.z + Bp.z + Cp.z) / 3);
+    }
+    out[0] = N.x; out[1] = N.y; out[2] = N.z; out[3] = dot(N, C);
+  }
+}
+
 }  // namespace msfl

@@ -85,3 +85,28 @@ def test_unsorted_rings_follow_reference_break_semantics(gpu, oracle):
     assert list(info_g.n_edge) == list(info_o.n_edge) and list(info_g.n_plane) == list(info_o.n_plane)
     dt, dr = synth.pose_error(pose_g, pose_o)
     assert dt < TIGHT and dr < TIGHT
+
+
+def test_tiled_throughput_kernel_equals_wave_latency_kernel(gpu, oracle):
+    """Small calls use one wavefront per query, large batches the LDS-tiled kernel (256 queries per
+    workgroup).  A 42-pair batch (tiled) must reproduce the single-pair calls (wave) bit for bit."""
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    base = [_clouds(*_pair(oracle, i)) for i in range(3)]
+    pairs = [base[i % 3] for i in range(42)]
+    guesses = np.stack([ident] * 42)
+    guesses[:, 0] = np.linspace(-0.05, 0.05, 42)              # distinct guesses -> distinct results
+    sets = []
+    for k in range(4):
+        pick = lambda p: (p[0], p[2], p[4], p[5])[k]
+        pts = np.concatenate([pick(p) for p in pairs])
+        off = np.cumsum([0] + [len(pick(p)) for p in pairs]).astype(np.int32)
+        ring = np.concatenate([(p[1], p[3])[k] for p in pairs]) if k < 2 else None
+        sets.append((pts, ring, off))
+    assert 42 * max(len(p[4]) + len(p[5]) for p in pairs) > 16384       # really on the tiled path
+    poses, status, _ = gpu.match_scan2scan_batch(sets, guesses)
+    assert np.all(status == 0)
+    for b in (0, 1, 2, 20, 41):
+        s, p, _ = gpu.match_scan2scan(*pairs[b], guesses[b])
+        assert s == 0 and np.array_equal(p, poses[b]), b
+    rc, pose_o, _ = oracle.match_scan2scan(*pairs[7], guesses[7])
+    assert max(synth.pose_error(poses[7], pose_o)) < TIGHT
