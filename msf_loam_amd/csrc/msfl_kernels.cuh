@@ -171,21 +171,28 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
   if (xs > xe) return;
   const float cell = 1.0f / g.inv_cell;
   const float cell2 = cell * cell;
-  // visit order of the 9 (dy,dz) rows: centre, 4 edge neighbours, 4 diagonal neighbours (value + 1, 2 bits each)
-  constexpr unsigned DY = 1u | (0u << 2) | (2u << 4) | (1u << 6) | (1u << 8) | (0u << 10) | (2u << 12) | (0u << 14) | (2u << 16);
-  constexpr unsigned DZ = 1u | (1u << 2) | (1u << 4) | (0u << 6) | (2u << 8) | (0u << 10) | (0u << 12) | (2u << 14) | (2u << 16);
+  // per-axis lower bounds for the three y and three z cell offsets, computed once
+  const float gy0 = axis_gap(uy, cy - 1), gy1 = axis_gap(uy, cy), gy2 = axis_gap(uy, cy + 1);
+  const float gz0 = axis_gap(uz, cz - 1), gz1 = axis_gap(uz, cz), gz2 = axis_gap(uz, cz + 1);
+  const float gxa = axis_gap(ux, xs), gxb = axis_gap(ux, xe);
+  const float gxa2 = gxa * gxa * cell2, gxb2 = gxb * gxb * cell2;
+  // visit order of the 9 (dy,dz) rows: centre, 4 edge neighbours, 4 diagonal neighbours.
+  // Fully unrolled: offsets are compile-time constants.
+  constexpr int DYS[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+  constexpr int DZS[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+#pragma unroll
   for (int r = 0; r < 9; r++) {
-    const int y = cy + (int)((DY >> (2 * r)) & 3u) - 1;
-    const int z = cz + (int)((DZ >> (2 * r)) & 3u) - 1;
+    const int y = cy + DYS[r], z = cz + DZS[r];
     if (y < 0 || y >= g.dy || z < 0 || z >= g.dz) continue;
-    const float gy = axis_gap(uy, y), gz = axis_gap(uz, z);
+    const float gy = DYS[r] < 0 ? gy0 : (DYS[r] == 0 ? gy1 : gy2);
+    const float gz = DZS[r] < 0 ? gz0 : (DZS[r] == 0 ? gz1 : gz2);
     const float row2 = (gy * gy + gz * gz) * cell2;
-    if (row2 > top5_d4(t)) continue;          // NaN (fewer than 5 found so far) never prunes
+    const float d4 = top5_d4(t);
+    if (row2 > d4) continue;                  // NaN (fewer than 5 found so far) never prunes
     // trim the x range: drop an end cell whose lower bound exceeds the 5th-best distance
     int a = xs, b = xe;
-    const float d4 = top5_d4(t);
-    { const float gx = axis_gap(ux, a); if (a < b && row2 + gx * gx * cell2 > d4) a++; }
-    { const float gx = axis_gap(ux, b); if (a < b && row2 + gx * gx * cell2 > d4) b--; }
+    if (a < b && row2 + gxa2 > d4) a++;
+    if (a < b && row2 + gxb2 > d4) b--;
     const int row = (z * g.dy + y) * g.dx;
     // x-adjacent cells are contiguous in the sorted array: one range per (y, z)
     const int s = cell_start[row + a], e = cell_start[row + b + 1];
