@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -76,7 +77,10 @@ struct PinRing {
 };
 
 struct MapIndex {
-  GridDesc g{};
+  DevBuf gdesc;        // GridDesc, computed on the device (no host round trip in msfl_set_map)
+  int cap_cells = 0;   // capacity of cell_start / count (cells)
+  // feedback for the table span of the next build (asynchronous read-back, never waited for)
+  int* want_host = nullptr; hipEvent_t want_ev = nullptr; bool want_pending = false; int span = 0;
   DevBuf sorted;      // float4[n]
   DevBuf pos_of;      // int[n]: original index -> position in `sorted`
   DevBuf cell_start;  // int[n_cells + 1]
@@ -98,6 +102,7 @@ struct msfl_handle_s {
 
   bool have_map = false;
   MapIndex map_c, map_s;
+  int grid_cap_cells = 64 * 1024 * 1024;  // hard limit of the dense cell table (MSFL_GRID_CAP_CELLS)
 
   // scratch
   DevBuf in_corner, in_surf, in_off, poses, status, info, records, pprime, nn;
@@ -177,69 +182,66 @@ SolverParams solver_params(const msfl_params& p, int min_corr) {
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
-// Build the exact-kNN grid over `pts` (device pointer, n points).
+// Build the exact-kNN grid over `pts` (device pointer, n points).  Fully asynchronous: the grid
+// descriptor is computed and kept on the device; the dense cell table has a fixed capacity
+// (default 4 M cells, MSFL_GRID_CAP_CELLS) and the device grows the cell edge if the map's bounding
+// box would need more (larger cells stay exact).
 msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) {
   ScopedTimer timer(h, T_INDEX);
   mi.n_input = n;
-  mi.g = GridDesc{};
-  if (n <= 0) return MSFL_OK;
   hipStream_t st = h->stream;
-  HIPCHK(h, h->idx_bbox.reserve(6 * sizeof(int)));
-  int init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
-  HIPCHK(h, h->pin.upload(h->idx_bbox.p, init, sizeof(init), st));
-  const int blocks = std::min(div_up(n, 256), 64);   // few blocks: the 6 atomics per wave contend on one line
-  hipLaunchKernelGGL(grid_bbox_kernel, dim3(blocks), dim3(256), 0, st, pts, n, h->idx_bbox.as<int>());
-  int bb[6];
-  HIPCHK(h, hipMemcpyAsync(bb, h->idx_bbox.p, sizeof(bb), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  if (bb[0] == INT32_MAX) return MSFL_OK;   // no finite point
-  float mn[3], mx[3];
-  for (int a = 0; a < 3; a++) { mn[a] = ordered_to_float(bb[a]); mx[a] = ordered_to_float(bb[3 + a]); }
-  // cell edge: >= 1.001 * acceptance radius (rigorous exactness under f32 rounding of the cell
-  // coordinate); grown if the dense table would exceed the cap (larger cells stay exact).
-  double cell = 1.001 * std::sqrt((double)h->prm.map_knn_max_sq_dist);
-  const double cap_cells = 64.0 * 1024 * 1024;
-  int dims[3];
-  for (;;) {
-    double total = 1.0;
-    for (int a = 0; a < 3; a++) {
-      dims[a] = (int)std::floor(((double)mx[a] - (double)mn[a]) / cell) + 1;
-      if (dims[a] < 1) dims[a] = 1;
-      total *= dims[a];
-    }
-    if (total <= cap_cells) break;
-    cell *= 1.26;
+  // span of the dense cell table: what the previous build of this map said it needs (+25 %), else 1 M
+  // cells.  The device grows the cell edge when the bounding box needs more than `cap` (still exact,
+  // just more candidates per cell), and reports the wanted size for the next build.
+  if (!mi.want_host) {
+    HIPCHK(h, hipHostMalloc((void**)&mi.want_host, sizeof(int), hipHostMallocDefault));
+    HIPCHK(h, hipEventCreateWithFlags(&mi.want_ev, hipEventDisableTiming));
+    *mi.want_host = 0;
   }
-  GridDesc g;
-  g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
-  g.inv_cell = (float)(1.0 / cell);
-  // f32 rounding of (v - o) * inv may land exactly on dim: one spare cell per axis
-  g.dx = dims[0] + 1; g.dy = dims[1] + 1; g.dz = dims[2] + 1;
-  g.n_cells = g.dx * g.dy * g.dz;
-  g.n_pts = 0;
-  HIPCHK(h, h->idx_cell_of.reserve((size_t)n * sizeof(int)));
-  HIPCHK(h, h->idx_count.reserve(((size_t)g.n_cells + 1) * sizeof(int)));
-  HIPCHK(h, mi.cell_start.reserve(((size_t)g.n_cells + 1) * sizeof(int)));
-  HIPCHK(h, mi.sorted.reserve((size_t)n * sizeof(float4)));
-  HIPCHK(h, mi.pos_of.reserve((size_t)n * sizeof(int)));
-  HIPCHK(h, hipMemsetAsync(h->idx_count.p, 0, ((size_t)g.n_cells + 1) * sizeof(int), st));
-  hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, g, h->idx_cell_of.as<int>(),
-                     h->idx_count.as<int>());
+  if (mi.want_pending && hipEventQuery(mi.want_ev) == hipSuccess) {
+    mi.want_pending = false;
+    const long long w = (long long)(*mi.want_host) + (*mi.want_host) / 4 + 1024;
+    mi.span = (int)std::min<long long>(std::max<long long>(w, 65536), h->grid_cap_cells);
+  }
+  if (mi.span <= 0) mi.span = std::min(1 << 20, h->grid_cap_cells);
+  const int cap = mi.span;
+  HIPCHK(h, mi.gdesc.reserve(sizeof(GridDesc)));
+  HIPCHK(h, h->idx_bbox.reserve(6 * sizeof(int)));
+  HIPCHK(h, h->idx_cell_of.reserve(std::max<size_t>(1, (size_t)n) * sizeof(int)));
+  HIPCHK(h, h->idx_count.reserve(((size_t)cap + 1) * sizeof(int)));
+  HIPCHK(h, mi.cell_start.reserve(((size_t)cap + 1) * sizeof(int)));
+  HIPCHK(h, mi.sorted.reserve(std::max<size_t>(1, (size_t)n) * sizeof(float4)));
+  HIPCHK(h, mi.pos_of.reserve(std::max<size_t>(1, (size_t)n) * sizeof(int)));
+  mi.cap_cells = cap;
+  const int init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
+  HIPCHK(h, h->pin.upload(h->idx_bbox.p, init, sizeof(init), st));
+  if (n > 0) {
+    const int blocks = std::min(div_up(n, 256), 64);   // few blocks: the 6 atomics per wave contend on one line
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(blocks), dim3(256), 0, st, pts, n, h->idx_bbox.as<int>());
+  }
+  hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1), 0, st, (const int*)h->idx_bbox.as<int>(),
+                     std::sqrt((double)h->prm.map_knn_max_sq_dist), cap, mi.gdesc.as<GridDesc>());
+  // the table is cleared / scanned over the cells actually used last time (+ margin) when known,
+  // else over the full capacity; the device never indexes beyond n_cells <= cap.
+  const size_t span = (size_t)cap + 1;
+  HIPCHK(h, hipMemsetAsync(h->idx_count.p, 0, span * sizeof(int), st));
+  if (n > 0)
+    hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, (const GridDesc*)mi.gdesc.as<GridDesc>(),
+                       h->idx_cell_of.as<int>(), h->idx_count.as<int>());
   size_t tmp_bytes = 0;
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(),
-                                             g.n_cells + 1, st));
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(), (int)span, st));
   HIPCHK(h, h->idx_cub.reserve(tmp_bytes));
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(h->idx_cub.p, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(),
-                                             g.n_cells + 1, st));
-  hipLaunchKernelGGL(grid_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, h->idx_cell_of.as<int>(),
-                     mi.cell_start.as<int>(), h->idx_count.as<int>(), mi.sorted.as<float4>(), mi.pos_of.as<int>());
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(h->idx_cub.p, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(), (int)span, st));
+  if (n > 0)
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, h->idx_cell_of.as<int>(),
+                       mi.cell_start.as<int>(), h->idx_count.as<int>(), mi.sorted.as<float4>(), mi.pos_of.as<int>());
+  hipLaunchKernelGGL(grid_finalize_kernel, dim3(1), dim3(1), 0, st, (const int*)mi.cell_start.as<int>(), mi.gdesc.as<GridDesc>());
   HIPCHK(h, hipGetLastError());
-  // number of indexed (finite) points = cell_start[n_cells]; only needed for the < 5 gate
-  int total = 0;
-  HIPCHK(h, hipMemcpyAsync(&total, mi.cell_start.as<int>() + g.n_cells, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  g.n_pts = total;
-  mi.g = g;
+  if (!mi.want_pending) {
+    HIPCHK(h, hipMemcpyAsync(mi.want_host, &mi.gdesc.as<GridDesc>()->want_cells, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipEventRecord(mi.want_ev, st));
+    mi.want_pending = true;
+  }
   return MSFL_OK;
 }
 
@@ -253,13 +255,13 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv, const double* d_poses, 
     ScopedTimer timer(h, T_ASSOC);
     if (deskew)
       hipLaunchKernelGGL(knn5_scan2map_kernel<true>, grid, block, 0, st, bv, d_poses, d_status,
-                         h->map_c.g, h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
-                         h->map_s.g, h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                         (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                         (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
                          h->prm.map_knn_max_sq_dist, dv, nn);
     else
       hipLaunchKernelGGL(knn5_scan2map_kernel<false>, grid, block, 0, st, bv, d_poses, d_status,
-                         h->map_c.g, h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
-                         h->map_s.g, h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                         (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                         (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
                          h->prm.map_knn_max_sq_dist, dv, nn);
   }
   {
@@ -323,7 +325,9 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
 
 msfl_status check_map(msfl_handle* h) {
   if (!h->have_map) return fail(h, MSFL_NO_MAP, "msfl_set_map has not been called on this handle");
-  if (h->map_c.g.n_pts < 5 || h->map_s.g.n_pts < 5)
+  // host-known input sizes; non-finite map points only ever reduce the candidate set (a query
+  // with fewer than 5 finite neighbours is rejected on the device like any other)
+  if (h->map_c.n_input < 5 || h->map_s.n_input < 5)
     return fail(h, MSFL_MAP_TOO_SMALL, "map corner/surf cloud has fewer than 5 points (mapping_scan_matcher.cc:128,198 would read out of bounds)");
   return MSFL_OK;
 }
@@ -396,6 +400,7 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
     return MSFL_HIP_ERROR;
   }
   h->stream = h->own_stream;
+  if (const char* e = std::getenv("MSFL_GRID_CAP_CELLS")) { const int c = std::atoi(e); if (c >= 8 && c <= (1 << 28)) h->grid_cap_cells = c; }
   *out = h;
   return MSFL_OK;
 }
@@ -407,7 +412,13 @@ void msfl_destroy(msfl_handle* h) {
   collect_timing(h);
   for (auto e : h->free_events) (void)hipEventDestroy(e);
   h->pin.release();
-  DevBuf* bufs[] = {&h->map_c.sorted, &h->map_c.cell_start, &h->map_s.sorted, &h->map_s.cell_start, &h->map_c.pos_of, &h->map_s.pos_of, &h->in_corner,
+  for (MapIndex* mi : {&h->map_c, &h->map_s}) {
+    if (mi->want_pending) (void)hipEventSynchronize(mi->want_ev);
+    if (mi->want_ev) (void)hipEventDestroy(mi->want_ev);
+    if (mi->want_host) (void)hipHostFree(mi->want_host);
+  }
+  DevBuf* bufs[] = {&h->map_c.sorted, &h->map_c.cell_start, &h->map_s.sorted, &h->map_s.cell_start, &h->map_c.pos_of, &h->map_s.pos_of,
+                    &h->map_c.gdesc, &h->map_s.gdesc, &h->in_corner,
                     &h->in_surf, &h->in_off, &h->poses, &h->status, &h->info, &h->records, &h->pprime, &h->nn,
                     &h->idx_cell_of, &h->idx_count, &h->idx_bbox, &h->idx_cub, &h->idx_stage};
   for (auto* b : bufs) b->release();
@@ -496,6 +507,9 @@ msfl_status msfl_set_map(msfl_handle* h, const msfl_point* corner, int n_corner,
   }
   s = build_index(h, dc, n_corner, h->map_c); if (s) return s;
   s = build_index(h, ds, n_surf, h->map_s); if (s) return s;
+  // host arrays were staged with asynchronous copies from pageable memory: they must have been read
+  // before the caller may touch them again.  Device-resident maps stay fully asynchronous.
+  if (mem == MSFL_MEM_HOST) HIPCHK(h, hipStreamSynchronize(h->stream));
   h->have_map = true;
   return MSFL_OK;
 }

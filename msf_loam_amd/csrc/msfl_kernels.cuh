@@ -31,6 +31,8 @@ struct GridDesc {
   int dx, dy, dz;
   int n_pts;          // finite points indexed
   int n_cells;
+  int reach;          // cells scanned on each side of the query cell (1)
+  int want_cells;     // cells the bbox needs at the base cell edge (saturated); host feedback for the next build
 };
 
 // order-preserving float <-> int encoding for atomicMin/Max
@@ -83,10 +85,46 @@ __device__ __forceinline__ int grid_coord(float v, float o, float inv, int dim) 
   return (int)u;
 }
 
-__global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restrict__ pts, int n, GridDesc g,
+// One thread: bbox -> grid descriptor, entirely on the device so that msfl_set_map needs no host
+// round trip.  Cell edge = 1.001 * acceptance radius, grown by 26 % steps until the dense table fits
+// `cap_cells` (larger cells stay exact).  An empty cloud yields n_cells = 1, n_pts = 0.
+__global__ void grid_setup_kernel(const int* __restrict__ bbox, double radius, int cap_cells, GridDesc* __restrict__ out) {
+  GridDesc g;
+  g.n_pts = 0; g.reach = 1;
+  if (bbox[0] == 0x7fffffff) {            // no finite point
+    g.ox = g.oy = g.oz = 0.f; g.inv_cell = 1.f; g.dx = g.dy = g.dz = 1; g.n_cells = 1; g.want_cells = 1;
+    *out = g;
+    return;
+  }
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; a++) { mn[a] = ordered_to_float(bbox[a]); mx[a] = ordered_to_float(bbox[3 + a]); }
+  double cell = 1.001 * radius;
+  int dims[3];
+  bool first = true;
+  g.want_cells = 1;
+  for (;;) {
+    double total = 1.0;
+    for (int a = 0; a < 3; a++) {
+      dims[a] = (int)floor(((double)mx[a] - (double)mn[a]) / cell) + 2;   // +1 spare cell: f32 rounding of (v-o)*inv
+      if (dims[a] < 2) dims[a] = 2;
+      total *= dims[a];
+    }
+    if (first) { g.want_cells = total < 2.0e9 ? (int)total : 2000000000; first = false; }
+    if (total <= (double)cap_cells) break;
+    cell *= 1.26;
+  }
+  g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+  g.inv_cell = (float)(1.0 / cell);
+  g.dx = dims[0]; g.dy = dims[1]; g.dz = dims[2];
+  g.n_cells = g.dx * g.dy * g.dz;
+  *out = g;
+}
+
+__global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restrict__ pts, int n, const GridDesc* __restrict__ gp,
                                                           int* __restrict__ cell_of, int* __restrict__ count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const GridDesc g = *gp;
   const float4 p = pts[i];
   int c = -1;
   if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
@@ -97,6 +135,11 @@ __global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restric
     atomicAdd(&count[c], 1);
   }
   cell_of[i] = c;
+}
+
+// after the exclusive scan: number of indexed (finite) points = cell_start[n_cells]
+__global__ void grid_finalize_kernel(const int* __restrict__ cell_start, GridDesc* __restrict__ g) {
+  g->n_pts = cell_start[g->n_cells];
 }
 
 // cursor[] holds the per-cell counts on entry and is consumed; the order inside a cell is
@@ -295,8 +338,8 @@ struct DeskewView {
 template <bool DESKEW>
 __global__ void __launch_bounds__(256)
 knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
-                     GridDesc gc, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
-                     GridDesc gs, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
+                     const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
+                     const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
                      float max_sq_dist, DeskewView dv, int* __restrict__ nn) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bv.n_records) return;
@@ -330,7 +373,8 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
     q = transform_point_f32(T, f.x, f.y, f.z);                          // :123 / :193
   }
   Top5 t;
-  if (is_edge) knn5_grid(gc, map_c, cs_c, q, t); else knn5_grid(gs, map_s, cs_s, q, t);
+  if (is_edge) { const GridDesc gc = *gcp; knn5_grid(gc, map_c, cs_c, q, t); }
+  else { const GridDesc gs = *gsp; knn5_grid(gs, map_s, cs_s, q, t); }
   if (t.k4 != ~0ull && (double)top5_d4(t) < (double)max_sq_dist) {      // :128 / :198
     out[0] = (int)(unsigned int)t.k0; out[1] = (int)(unsigned int)t.k1; out[2] = (int)(unsigned int)t.k2;
     out[3] = (int)(unsigned int)t.k3; out[4] = (int)(unsigned int)t.k4;   // original map indices, nearest first
