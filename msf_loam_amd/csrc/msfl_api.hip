@@ -257,22 +257,24 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv, const double* d_poses, 
       hipLaunchKernelGGL(knn5_scan2map_kernel<true>, grid, block, 0, st, bv, d_poses, d_status,
                          (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
                          (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                         (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
                          h->prm.map_knn_max_sq_dist, dv, nn);
     else
       hipLaunchKernelGGL(knn5_scan2map_kernel<false>, grid, block, 0, st, bv, d_poses, d_status,
                          (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
                          (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                         (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
                          h->prm.map_knn_max_sq_dist, dv, nn);
   }
   {
     ScopedTimer timer(h, T_FIT);
     if (deskew)
-      hipLaunchKernelGGL(fit_scan2map_kernel<true>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(), h->map_c.pos_of.as<int>(),
-                         h->map_s.sorted.as<float4>(), h->map_s.pos_of.as<int>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
+      hipLaunchKernelGGL(fit_scan2map_kernel<true>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(),
+                         h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
                          h->records.as<double>(), full);
     else
-      hipLaunchKernelGGL(fit_scan2map_kernel<false>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(), h->map_c.pos_of.as<int>(),
-                         h->map_s.sorted.as<float4>(), h->map_s.pos_of.as<int>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
+      hipLaunchKernelGGL(fit_scan2map_kernel<false>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(),
+                         h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
                          h->records.as<double>(), full);
   }
 }

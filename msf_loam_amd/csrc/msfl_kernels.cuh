@@ -333,13 +333,14 @@ struct DeskewView {
 };
 
 // K4a: transform + exact 5-NN.  Low register count (no f64 fits here) -> 8 waves/SIMD to hide the
-// latency of the scattered 16-byte candidate loads.  nn[5*g..] = original map indices (nearest first),
+// latency of the scattered 16-byte candidate loads.  nn[5*g..] = positions in the sorted map (nearest first),
 // nn[5*g] = -1 when the feature is rejected by the `pointSearchSqDis[4] < 1.0` gate (:128 / :198).
 template <bool DESKEW>
 __global__ void __launch_bounds__(256)
 knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
                      const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
                      const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
+                     const int* __restrict__ pos_c, const int* __restrict__ pos_s,
                      float max_sq_dist, DeskewView dv, int* __restrict__ nn) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bv.n_records) return;
@@ -376,8 +377,11 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   if (is_edge) { const GridDesc gc = *gcp; knn5_grid(gc, map_c, cs_c, q, t); }
   else { const GridDesc gs = *gsp; knn5_grid(gs, map_s, cs_s, q, t); }
   if (t.k4 != ~0ull && (double)top5_d4(t) < (double)max_sq_dist) {      // :128 / :198
-    out[0] = (int)(unsigned int)t.k0; out[1] = (int)(unsigned int)t.k1; out[2] = (int)(unsigned int)t.k2;
-    out[3] = (int)(unsigned int)t.k3; out[4] = (int)(unsigned int)t.k4;   // original map indices, nearest first
+    // original map index -> position in the sorted map array (the fit kernel then gathers directly);
+    // done here because this kernel runs at 8 waves/SIMD and hides the extra dependent load
+    const int* po = is_edge ? pos_c : pos_s;
+    out[0] = po[(unsigned int)t.k0]; out[1] = po[(unsigned int)t.k1]; out[2] = po[(unsigned int)t.k2];
+    out[3] = po[(unsigned int)t.k3]; out[4] = po[(unsigned int)t.k4];       // nearest first
   } else {
     out[0] = -1;
   }
@@ -388,8 +392,8 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
 // `full` (optional, debug/parity API) receives {C, N} for every feature.
 template <bool DESKEW>
 __global__ void __launch_bounds__(256)
-fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const int* __restrict__ pos_c,
-                    const float4* __restrict__ map_s, const int* __restrict__ pos_s, const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
+fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
+                    const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
                     double* __restrict__ rec, double* __restrict__ full) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bv.n_records) return;
@@ -402,8 +406,7 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const int* _
   const int p0 = in[0];
   if (p0 >= 0) {
     const float4* mp = is_edge ? map_c : map_s;
-    const int* po = is_edge ? pos_c : pos_s;
-    const float4 nb[5] = {mp[po[p0]], mp[po[in[1]]], mp[po[in[2]]], mp[po[in[3]]], mp[po[in[4]]]};
+    const float4 nb[5] = {mp[p0], mp[in[1]], mp[in[2]], mp[in[3]], mp[in[4]]};
     fo = is_edge ? edge_fit(nb, line_ratio) : plane_fit(nb, plane_tol);
     if (DESKEW && fo.ok) {
       // C' = C - (Vi dt - G dt^2/2): the velocity block is constant (mapping_scan_matcher.cc:94)

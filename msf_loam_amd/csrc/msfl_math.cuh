@@ -120,6 +120,7 @@ struct sym3 { double a00, a01, a02, a11, a12, a22; };
 
 template <int P, int Q>
 __device__ __forceinline__ void jacobi_rotate(double (&a)[3][3], double (&v)[3][3]) {
+#pragma clang fp contract(fast)
   const double apq = a[P][Q];
   if (apq == 0.0) return;
   const double theta = (a[Q][Q] - a[P][P]) / (2.0 * apq);
@@ -177,6 +178,7 @@ __device__ __forceinline__ void sym_eigen3_top(const sym3& S, double& ev_mid, do
 template <int K>
 __device__ __forceinline__ void qr_step(double (&A)[5][3], double (&b)[5], int (&perm)[3], double (&diag)[3],
                                         double& maxpivot) {
+#pragma clang fp contract(fast)   // f64 fits: FMA only changes rounding at 1e-16, far inside the 1e-9 record tolerance
   // pivot: remaining column with the largest norm below row K (first wins ties)
   double cn[3] = {0, 0, 0};
 #pragma unroll
