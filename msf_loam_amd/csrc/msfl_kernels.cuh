@@ -505,12 +505,25 @@ __device__ __forceinline__ void huber_rho(double a, double s, double& rho0, doub
 
 // One evaluation pass of a scan's records at pose T: cost, g = J^T r, H = J^T J (robustified,
 // tangent space).  lidar_factor.cc:7-44 + Ceres HuberLoss/Corrector.
-template <int BLOCK>
+// LDS-resident copy of the first K plane records + their points (44 B each, structure of arrays so
+// that consecutive lanes hit consecutive banks).  A solve re-reads every record in each of its ~4-7
+// evaluation passes: what fits here is fetched from HBM once per solve instead of once per pass.
+constexpr int kPlaneCache = 1728;     // 76 KB -> two 256-thread workgroups per CU
+struct PlaneCache {
+  double nx[kPlaneCache], ny[kPlaneCache], nz[kPlaneCache], d0[kPlaneCache];
+  float px[kPlaneCache], py[kPlaneCache], pz[kPlaneCache];
+};
+
+// FILL: first pass of a solve (records come from global memory and are copied into the cache);
+// later passes read the cached part from LDS.  A thread only ever re-reads entries it wrote itself
+// (same i -> thread mapping in every pass), so no barrier is needed around the cache.
+template <int BLOCK, bool FILL>
 __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
                                               const float4* __restrict__ corner, int nc,
                                               const float4* __restrict__ surf, int ns,
                                               const double* __restrict__ pprime,   // may be null
                                               const double* __restrict__ rec,      // this scan's records
+                                              PlaneCache& pc,
                                               double (&acc)[kAcc], int& n_edge, int& n_plane) {
 #pragma unroll
   for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
@@ -538,14 +551,26 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   }
   // planes: {N, N.C}, r = N.(R p + t) - N.C                                    lidar_factor.cc:32
   const double* recp = rec + 6 * (size_t)nc;
+  const bool use_cache = (pprime == nullptr);       // deskew keeps f64 points in global memory
   for (int i = threadIdx.x; i < ns; i += BLOCK) {
-    const double* r4 = recp + 4 * (size_t)i;
-    const d3 N = mk3(r4[0], r4[1], r4[2]);
-    const double d0 = r4[3];
-    if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) continue;
-    d3 p;
-    if (pprime) { const size_t k = (size_t)(nc + i); p = mk3(pprime[3 * k], pprime[3 * k + 1], pprime[3 * k + 2]); }
-    else { const float4 f = surf[i]; p = mk3((double)f.x, (double)f.y, (double)f.z); }     // :221
+    d3 N, p; double d0;
+    if (!FILL && use_cache && i < kPlaneCache) {
+      N = mk3(pc.nx[i], pc.ny[i], pc.nz[i]); d0 = pc.d0[i];
+      p = mk3((double)pc.px[i], (double)pc.py[i], (double)pc.pz[i]);
+    } else {
+      const double* r4 = recp + 4 * (size_t)i;
+      N = mk3(r4[0], r4[1], r4[2]); d0 = r4[3];
+      if (pprime) { const size_t k = (size_t)(nc + i); p = mk3(pprime[3 * k], pprime[3 * k + 1], pprime[3 * k + 2]); }
+      else {
+        const float4 f = surf[i];                              // curr_point: untransformed (:221)
+        p = mk3((double)f.x, (double)f.y, (double)f.z);
+        if (FILL && i < kPlaneCache) {
+          pc.nx[i] = N.x; pc.ny[i] = N.y; pc.nz[i] = N.z; pc.d0[i] = d0;
+          pc.px[i] = f.x; pc.py[i] = f.y; pc.pz[i] = f.z;
+        }
+      }
+    }
+    if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) continue;      // rejected correspondence
     n_plane++;
     const double r = dot(N, quat_rotate(T.q, p) + T.t) - d0;
     double rho0, rho1; huber_rho(huber, r * r, rho0, rho1);
@@ -803,11 +828,12 @@ __device__ __noinline__ int tr_decide(TrState& tr, const double* red, const Solv
 // evaluates cost AND the normal equations at the candidate, so an accepted step needs no second
 // pass (Ceres re-evaluates; the values are identical).
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 3)
+__global__ void __launch_bounds__(BLOCK, 2)
 lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const double* __restrict__ rec_all,
                 double* __restrict__ poses, int* __restrict__ status, DevMatchInfo* __restrict__ info,
                 int outer_it, SolverParams prm) {
   __shared__ LmShared<BLOCK> sh;
+  __shared__ PlaneCache s_cache;
   const int b = blockIdx.x;
   if (status[b] != 0) return;
   const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
@@ -824,7 +850,7 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
     double acc[kAcc];
     int ne, np;
     const pose7 T = load_pose(pose_g);
-    evaluate_pass<BLOCK>(T, prm.huber, corner, nc, surf, ns, pprime, rec, acc, ne, np);
+    evaluate_pass<BLOCK, true>(T, prm.huber, corner, nc, surf, ns, pprime, rec, s_cache, acc, ne, np);
     block_reduce<BLOCK>(sh, acc, ne, np);
   }
   if (threadIdx.x == 0) {
@@ -865,7 +891,7 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
     int ne, np;
     const pose7 T = load_pose(tr.cand);
     __syncthreads();                       // everyone has read go / cand before lane 0 may overwrite them
-    evaluate_pass<BLOCK>(T, prm.huber, corner, nc, surf, ns, pprime, rec, acc, ne, np);
+    evaluate_pass<BLOCK, false>(T, prm.huber, corner, nc, surf, ns, pprime, rec, s_cache, acc, ne, np);
     block_reduce<BLOCK>(sh, acc, ne, np);
     if (threadIdx.x == 0) sh.go = tr_decide(tr, sh.red, prm) ? tr_propose(tr, prm) : 0;
     __syncthreads();
