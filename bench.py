@@ -191,6 +191,18 @@ def main():
         solve_ms = timing.ms_solve / max(timing.launches_solve, 1)
         index_ms = timing.ms_index / max(timing.launches_index, 1)
         achieved = alg_bytes_assoc / (assoc_ms * 1e-3) / 1e9 if assoc_ms > 0 else 0.0
+        # HBM traffic of the dominant kernel: PMC counters cannot be sampled from inside this process, so
+        # the figure comes from the committed rocprofv3 --pmc profile of this same command
+        # (profiles/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch), or null.
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            if B == 1024 and args.map_points == 200000:
+                traffic = pt["kernels"]["knn5_scan2map_kernel<false>"]["hbm_bytes_per_launch"]
+                traffic_src = pt["source"]
+        except Exception:
+            pass
         out = {
             "metric": "scan-to-map registrations/s", "value": value, "unit": "registrations/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -201,8 +213,8 @@ def main():
                        "scans_per_gpu": B, "map_points": n_mc + n_ms, "map_corner": n_mc, "map_surf": n_ms,
                        "features_per_scan": F_total / B, "feature_source": feature_source,
                        "index_rebuilt_per_step": True, "parallelism": "scan-sharded x%d, map replicated" % world_size},
-            "roofline": {"bound": "hbm", "kernel": "assoc_scan2map_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "knn5_scan2map_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes_assoc, "avg_launch_ms": assoc_ms},
             "kernels_ms": {"assoc": assoc_ms, "fit": timing.ms_fit / max(timing.launches_fit, 1), "solve": solve_ms,
                            "index_build": index_ms,
