@@ -4,9 +4,10 @@
 //   extract_prepare_kernel    one 1024-thread workgroup per scan: invalid-point removal (:85-111),
 //                             relative time (:128-156), stable split into rings + concat (:188-195)
 //   extract_curvature_kernel  one thread per point: 11-tap curvature (:213-240) + neighbour-gap flags
-//   extract_pick_kernel       one wavefront per (scan, ring): per-sector LDS bitonic sort of
-//                             (curvature, index) keys (:263-267) + the serial sharp / less-sharp / flat
-//                             pick with neighbour suppression on LDS bitmasks (:270-344)
+//   extract_sort_kernel       one wavefront per (scan, ring, sector): LDS bitonic sort of 64-bit
+//                             (curvature, index) keys (:263-267)
+//   extract_pick_kernel       one wavefront per (scan, ring): the serial sharp / less-sharp / flat pick
+//                             with neighbour suppression on LDS bitmasks (:270-344)
 //   extract_compact_kernel    per scan: order the per-ring lists into the reference's push order,
 //                             apply the lidar->imu extrinsic (:367-371)
 // All index outputs are bit-exact w.r.t. the CPU oracle; the unstable std::sort tie order of the
@@ -45,7 +46,7 @@ struct ExtractView {
   int* ring_tab;               // n_scans x (kMaxRings + 1): ring start offsets (scan-local)
   int* tmp_idx;                // 4 x n_total: per-ring lists before compaction
   int* ring_cnt;               // n_scans x kMaxRings x 4
-  unsigned long long* sortbuf; // n_total: global fallback for sectors > kSortLds
+  unsigned long long* sortbuf; // 2 x n_total: sorted sector keys (sector at 2*(o+sp))
 };
 
 __device__ __forceinline__ bool point_valid(float4 p, double min_range) {
@@ -212,10 +213,10 @@ __global__ void __launch_bounds__(256) extract_curvature_kernel(ExtractView v, E
 template <class KeyPtr>
 __device__ __forceinline__ void wave_bitonic_sort(KeyPtr keys, int P, int lane) {
   for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
+    for (int j = k >> 1, lj = 31 - __clz(k >> 1); j > 0; j >>= 1, lj--) {
       for (int t = lane; t < (P >> 1); t += 64) {
-        // t-th compare-exchange pair of this stage
-        const int lo = ((t / j) * (j << 1)) + (t % j);
+        // t-th compare-exchange pair of this stage; j is a power of two: shifts, no division
+        const int lo = ((t >> lj) << (lj + 1)) + (t & (j - 1));
         const int hi = lo + j;
         const bool up = ((lo & k) == 0);
         const unsigned long long a = keys[lo], c = keys[hi];
@@ -225,6 +226,50 @@ __device__ __forceinline__ void wave_bitonic_sort(KeyPtr keys, int P, int lane) 
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+  }
+}
+
+// One wavefront per (scan, ring, sector): sort the sector's (curvature, index) keys ascending and
+// leave them at sortbuf[2*(o+sp) ...] (cnt entries).  Splitting the sort from the (serial) pick gives
+// six times more wavefronts for the part that dominates the instruction count.
+__global__ void __launch_bounds__(256) extract_sort_kernel(ExtractView v, ExtractParams prm) {
+  __shared__ unsigned long long s_keys[4][kSortLds];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  const int unit = blockIdx.x * 4 + wave;                 // ring * sectors + sector
+  const int r = unit / prm.sectors, j = unit - r * prm.sectors;
+  if (r >= kMaxRings || v.status[b] != 0) return;
+  const int* tab = v.ring_tab + b * (kMaxRings + 1);
+  const int s = tab[r], len = tab[r + 1] - tab[r];
+  const int start = s + 5, end = s + len - 6;
+  if (len <= 0 || end - start < 6 || len > kRingCapacity) return;
+  const int sp = start + (end - start) * j / prm.sectors;
+  const int ep = start + (end - start) * (j + 1) / prm.sectors - 1;
+  const int cnt = ep - sp + 1;
+  if (cnt <= 0) return;
+  const int o = v.off[b];
+  const float* curv = v.curvature + o;
+  unsigned long long* dst = v.sortbuf + 2 * (size_t)(o + sp);   // 2*cnt >= P entries: disjoint per sector
+  int P = 1;
+  while (P < cnt) P <<= 1;
+  // keys: (curvature bits << 32) | index.  curvature >= 0, so the f32 bit pattern is monotone and
+  // the u64 order is exactly (curvature, index) ascending.
+  if (P <= kSortLds) {
+    unsigned long long* keys = s_keys[wave];
+    for (int k = lane; k < P; k += 64)
+      keys[k] = (k < cnt) ? (((unsigned long long)__float_as_uint(curv[sp + k]) << 32) | (unsigned int)(sp + k)) : ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_bitonic_sort(keys, P, lane);
+    for (int k = lane; k < cnt; k += 64) dst[k] = keys[k];
+  } else {
+    for (int k = lane; k < P; k += 64)
+      dst[k] = (k < cnt) ? (((unsigned long long)__float_as_uint(curv[sp + k]) << 32) | (unsigned int)(sp + k)) : ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    wave_bitonic_sort(dst, P, lane);
   }
 }
 
@@ -280,33 +325,20 @@ __global__ void __launch_bounds__(256) extract_pick_kernel(ExtractView v, Extrac
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  unsigned long long* gkeys = v.sortbuf + o + s;      // global fallback region of this ring (len entries)
   for (int j = 0; j < prm.sectors; j++) {
     const int sp = start + (end - start) * j / prm.sectors;                 // :256-259
     const int ep = start + (end - start) * (j + 1) / prm.sectors - 1;
     const int cnt = ep - sp + 1;
     if (cnt <= 0) continue;
-    int P = 1;
-    while (P < cnt) P <<= 1;
-    const bool in_lds = (P <= kSortLds);
-    // keys: (curvature bits << 32) | index.  curvature >= 0, so the f32 bit pattern is monotone and
-    // the u64 order is exactly (curvature, index) ascending.
+    // sorted (curvature, index) keys of this sector, produced by extract_sort_kernel
+    const unsigned long long* gkeys = v.sortbuf + 2 * (size_t)(o + sp);
+    const bool in_lds = (cnt <= kSortLds);
     if (in_lds) {
       unsigned long long* keys = s_keys[wave];
-      for (int k = lane; k < P; k += 64)
-        keys[k] = (k < cnt) ? (((unsigned long long)__float_as_uint(curv[sp + k]) << 32) | (unsigned int)(sp + k)) : ~0ull;
+      for (int k = lane; k < cnt; k += 64) keys[k] = gkeys[k];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      wave_bitonic_sort(keys, P, lane);
-    } else {
-      // P <= 2*cnt - 1 <= len holds for every sector of a ring that passed the `end-start >= 6` gate
-      for (int k = lane; k < P; k += 64)
-        gkeys[k] = (k < cnt) ? (((unsigned long long)__float_as_uint(curv[sp + k]) << 32) | (unsigned int)(sp + k)) : ~0ull;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      wave_bitonic_sort(gkeys, P, lane);
     }
     if (lane == 0) {
       const unsigned long long* keys = in_lds ? s_keys[wave] : gkeys;

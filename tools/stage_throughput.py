@@ -1,0 +1,63 @@
+"""Throughput of stage A (feature extraction) and stage B (scan-to-scan) on device-resident batches.
+Run on the GPU box: python tools/stage_throughput.py [B]"""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from msf_loam_amd import capi, synth
+import ctypes as C
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dev = torch.device("cuda", 0)
+world = synth.World(ground_half=synth.ground_half_for_target(200000))
+poses = synth.random_poses(B, synth.SEED + 900)
+rng = np.random.default_rng(9)
+scans = [synth.make_scan(world, poses[i], synth.SEED + 901 + i) for i in range(B)]
+nxt = [synth.make_scan(world, synth.perturb_pose(poses[i], rng, 0.25, 2.0), synth.SEED + 5901 + i) for i in range(B)]
+h = capi.Handle(0)
+h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+def dev_extract(clouds):
+    pts = np.concatenate([p for p, _ in clouds]); ring = np.concatenate([r for _, r in clouds])
+    off = np.cumsum([0] + [len(p) for p, _ in clouds]).astype(np.int32)
+    n = len(pts)
+    d = dict(pts=torch.from_numpy(pts).to(dev), ring=torch.from_numpy(ring.astype(np.int16)).to(dev))
+    out = dict(full=torch.empty((n, 4), dtype=torch.float32, device=dev), fring=torch.empty(n, dtype=torch.int16, device=dev),
+               curv=torch.empty(n, dtype=torch.float32, device=dev), label=torch.empty(n, dtype=torch.uint8, device=dev),
+               idx=[torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4)],
+               cnt=[torch.empty(len(clouds), dtype=torch.int32, device=dev) for _ in range(5)],
+               status=torch.empty(len(clouds), dtype=torch.int32, device=dev))
+    f = capi.FeaturesBatch()
+    f.full_pts, f.full_ring, f.curvature, f.label = out["full"].data_ptr(), out["fring"].data_ptr(), out["curv"].data_ptr(), out["label"].data_ptr()
+    f.sharp_idx, f.less_sharp_idx, f.flat_idx, f.less_flat_idx = (t.data_ptr() for t in out["idx"])
+    f.n_full, f.n_sharp, f.n_less_sharp, f.n_flat, f.n_less_flat = (t.data_ptr() for t in out["cnt"])
+    def run():
+        s = h.lib.msfl_extract_features_batch(h.h, C.c_int(len(clouds)), C.c_void_p(d["pts"].data_ptr()), C.c_void_p(d["ring"].data_ptr()),
+                                              off.ctypes.data_as(C.c_void_p), C.byref(f), C.c_void_p(out["status"].data_ptr()), C.c_int(capi.MEM_DEVICE))
+        assert s == 0, s
+    return run, out, off, n
+
+run, out, off, n = dev_extract(scans)
+for _ in range(3): run()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+K = 10
+for _ in range(K): run()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+res = {"extract": {"scans": B, "points": int(n), "ms_per_batch": 1e3 * dt, "scans_per_s": B / dt,
+                   "GB_per_s_algorithmic(32B/pt)": 32 * n / dt / 1e9}}
+# stage B on host-staged batch (throughput kernel path)
+fa = h.extract_features_batch(np.concatenate([p for p, _ in scans]), np.concatenate([r for _, r in scans]), off)
+offb = np.cumsum([0] + [len(p) for p, _ in nxt]).astype(np.int32)
+fb = h.extract_features_batch(np.concatenate([p for p, _ in nxt]), np.concatenate([r for _, r in nxt]), offb)
+def cat(fs, key, ring=False):
+    pts = np.concatenate([f["full"][f[key]] for f in fs]); o = np.cumsum([0] + [len(f[key]) for f in fs]).astype(np.int32)
+    rg = np.concatenate([f["ring"][f[key]] for f in fs]) if ring else None
+    return (pts, rg, o)
+sets = [cat(fa, "less_sharp", True), cat(fa, "less_flat", True), cat(fb, "sharp"), cat(fb, "flat")]
+ident = np.tile([0, 0, 0, 0, 0, 0, 1.0], (B, 1))
+h.set_timing(True); h.get_timing(True)
+for _ in range(2): poses_o, st, _ = h.match_scan2scan_batch(sets, ident)
+t = h.get_timing(True)
+res["scan2scan"] = {"pairs": B, "ok": int((st == 0).sum()), "assoc_ms_per_launch": t.ms_odom / max(t.launches_odom, 1),
+                    "solve_ms_per_launch": t.ms_solve / max(t.launches_solve, 1),
+                    "pairs_per_s_gpu_only": B / (2 * (t.ms_odom / max(t.launches_odom, 1) + t.ms_solve / max(t.launches_solve, 1)) * 1e-3)}
+print(json.dumps(res))
