@@ -235,8 +235,11 @@ __device__ __forceinline__ void wave_bitonic_sort(KeyPtr keys, int P, int lane) 
 __global__ void __launch_bounds__(256) extract_sort_kernel(ExtractView v, ExtractParams prm) {
   __shared__ unsigned long long s_keys[4][kSortLds];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.y;
-  const int unit = blockIdx.x * 4 + wave;                 // ring * sectors + sector
+  // grid = (scans, unit groups): scans on the FAST block index.  Only the first few unit groups of a
+  // scan have work (16 of 128 rings on a VLP-16); with groups on the fast index the busy workgroups
+  // shared a residue mod 32 and the round-robin dispatcher packed them onto 32 of the 256 CUs.
+  const int b = blockIdx.x;
+  const int unit = blockIdx.y * 4 + wave;                 // ring * sectors + sector
   const int r = unit / prm.sectors, j = unit - r * prm.sectors;
   if (r >= kMaxRings || v.status[b] != 0) return;
   const int* tab = v.ring_tab + b * (kMaxRings + 1);
@@ -274,19 +277,43 @@ __global__ void __launch_bounds__(256) extract_sort_kernel(ExtractView v, Extrac
 }
 
 struct RingBits {
-  unsigned int* w;   // LDS words
+  unsigned int* w;   // LDS words (one spare word past the ring so that 64-bit windows never run out)
   __device__ __forceinline__ bool get(int i) const { return (w[i >> 5] >> (i & 31)) & 1u; }
   __device__ __forceinline__ void set(int i) { w[i >> 5] |= (1u << (i & 31)); }
+  // bits [i, i+32) as one word
+  __device__ __forceinline__ unsigned int window(int i) const {
+    const unsigned long long two = (unsigned long long)w[i >> 5] | ((unsigned long long)w[(i >> 5) + 1] << 32);
+    return (unsigned int)(two >> (i & 31));
+  }
+  // OR `bits` (<= 32 of them) in at position i
+  __device__ __forceinline__ void or_window(int i, unsigned int bits) {
+    const unsigned long long m = (unsigned long long)bits << (i & 31);
+    w[i >> 5] |= (unsigned int)m;
+    const unsigned int hi = (unsigned int)(m >> 32);
+    if (hi) w[(i >> 5) + 1] |= hi;
+  }
 };
+
+// Neighbour suppression of one pick at ring-local position q (msf_loam_node.cc:290-304 / :322-335):
+// forward l = 1..5 while the gap between q+l-1 and q+l is small, backward l = -1..-5 likewise.
+// Returns the marked span [q - back, q + fwd] as counts; bit arithmetic on one 32-bit window of
+// the gap mask instead of ten dependent LDS round trips.
+__device__ __forceinline__ void neighbour_span(const RingBits& gap, int q, int& back, int& fwd) {
+  const unsigned int g = gap.window(q - 5);          // bit t <-> gap between (q-5+t) and (q-5+t+1)
+  const unsigned int f5 = (g >> 5) & 31u;            // gaps q..q+4
+  fwd = __ffs((int)(f5 | 32u)) - 1;                  // first set gap stops the run (0..5)
+  const unsigned int b5 = g & 31u;                   // gaps q-5..q-1 ; walk down from q-1
+  back = __clz((int)((b5 << 27) | (1u << 26)));      // leading zeros of the 5-bit field (0..5)
+}
 
 __global__ void __launch_bounds__(256) extract_pick_kernel(ExtractView v, ExtractParams prm) {
   __shared__ unsigned long long s_keys[4][kSortLds];
-  __shared__ unsigned int s_picked[4][kRingCapacity / 32];
-  __shared__ unsigned int s_corner[4][kRingCapacity / 32];
-  __shared__ unsigned int s_gap[4][kRingCapacity / 32];
+  __shared__ unsigned int s_picked[4][kRingCapacity / 32 + 2];
+  __shared__ unsigned int s_corner[4][kRingCapacity / 32 + 2];
+  __shared__ unsigned int s_gap[4][kRingCapacity / 32 + 2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.y;
-  const int r = blockIdx.x * 4 + wave;
+  const int b = blockIdx.x;                               // scans on the fast block index (see extract_sort_kernel)
+  const int r = blockIdx.y * 4 + wave;
   if (r >= kMaxRings) return;
   int* cnt_out = v.ring_cnt + ((size_t)b * kMaxRings + r) * 4;
   const int* tab = v.ring_tab + b * (kMaxRings + 1);
@@ -312,7 +339,7 @@ __global__ void __launch_bounds__(256) extract_pick_kernel(ExtractView v, Extrac
   int* t_lf = v.tmp_idx + 3 * (size_t)v.n_total + o + s;
   RingBits picked{s_picked[wave]}, corner{s_corner[wave]}, gap{s_gap[wave]};
   // ring-local bitmasks: bit k <-> scan-local index s + k
-  for (int w0 = 0; w0 < len; w0 += 64) {
+  for (int w0 = 0; w0 < len + 64; w0 += 64) {       // one extra round: the spare words behind the ring
     const int k = w0 + lane;
     const bool gbit = (k < len) ? (gapb[s + k] != 0) : true;
     const unsigned long long m = __ballot(gbit);
@@ -359,15 +386,11 @@ __global__ void __launch_bounds__(256) extract_pick_kernel(ExtractView v, Extrac
         } else {
           break;
         }
-        picked.set(q); corner.set(q);
-        for (int l = 1; l <= 5; l++) {
-          if (gap.get(q + l - 1)) break;                     // |p[ind+l] - p[ind+l-1]|^2 > 0.05
-          picked.set(q + l); corner.set(q + l); label[ind + l] = 2;
-        }
-        for (int l = -1; l >= -5; l--) {
-          if (gap.get(q + l)) break;                         // |p[ind+l] - p[ind+l+1]|^2 > 0.05
-          picked.set(q + l); corner.set(q + l); label[ind + l] = 2;
-        }
+        int back, fwd;
+        neighbour_span(gap, q, back, fwd);                   // runs of |p[i+1]-p[i]|^2 <= 0.05 around q
+        const unsigned int span = (2u << (back + fwd)) - 1u; // back + fwd + 1 ones
+        picked.or_window(q - back, span); corner.or_window(q - back, span);
+        for (int l = -back; l <= fwd; l++) if (l != 0) label[ind + l] = 2;
       }
       // flat picks, ascending curvature (:307-336)
       int smallest = 0;
@@ -381,9 +404,9 @@ __global__ void __launch_bounds__(256) extract_pick_kernel(ExtractView v, Extrac
         label[ind] = 3; t_flat[n_flat++] = ind;
         smallest++;
         if (smallest >= prm.max_flat) break;                 // before neighbour marking, :317-319
-        picked.set(q);
-        for (int l = 1; l <= 5; l++) { if (gap.get(q + l - 1)) break; picked.set(q + l); }
-        for (int l = -1; l >= -5; l--) { if (gap.get(q + l)) break; picked.set(q + l); }
+        int back, fwd;
+        neighbour_span(gap, q, back, fwd);
+        picked.or_window(q - back, (2u << (back + fwd)) - 1u);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
