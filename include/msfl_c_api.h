@@ -337,6 +337,39 @@ msfl_status msfl_voxel_downsample(msfl_handle* h,
                                   const msfl_point* pts, int n, float leaf,
                                   msfl_point* out, int* n_out, msfl_mem mem);
 
+/* ------------------------------------------------------------------------------------------ */
+/* next row N1: the local map store kept resident on the device.               */
+/*   replaces HybridGrid (src/slam/map/hybrid_grid.h:27-39, hybrid_grid.cc:462-534), owned by   */
+/*   LaserMapping as hybrid_grid_map_corner_ / hybrid_grid_map_surf_ (laser_mapping.h:77-78).   */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct msfl_grid_s msfl_grid;
+
+/* HybridGrid(resolution) (laser_mapping.cc:44-45: 3.0 m cells) plus the leaf of the pcl::VoxelGrid its
+   owner passes to InsertScan (laser_mapping.cc:60-68: 0.2 corner / 0.4 surf).  The grid works on
+   `h`'s stream and must be destroyed before `h`. */
+msfl_status msfl_grid_create(msfl_handle* h, float resolution, float leaf, msfl_grid** out);
+void msfl_grid_destroy(msfl_grid* g);
+
+/* HybridGrid::InsertScan (hybrid_grid.cc:503-521): append every point to the cell
+   lround(p / resolution) and VoxelGrid-filter the touched cells in place.  `pts` are in the map
+   frame (the caller transforms them, laser_mapping.cc:330-338).  MSFL_CAPACITY if a point leaves
+   the +-8192-cell range of the reference (the map is then left unchanged). */
+msfl_status msfl_grid_insert_scan(msfl_grid* g, const msfl_point* pts, int n, msfl_mem mem);
+
+/* HybridGrid::GetSurroundedCloud (hybrid_grid.cc:470-501): union of the cells hit by
+   pose_f32 * p + (i,j,k) m, (i,j,k) in {-1,0,1}^3, over the scan points with |p| <= 60 m.
+   `scan` is in the scan frame, pose7 maps scan -> map.  Cells come out in ascending (iz,iy,ix)
+   order (the reference iterates an unordered set: unspecified).  *n_out receives the full count;
+   MSFL_CAPACITY if it exceeds `capacity` (the first `capacity` points are still written).
+   With MSFL_MEM_DEVICE the result can be handed straight to msfl_set_map. */
+msfl_status msfl_grid_get_surrounded(msfl_grid* g, const msfl_point* scan, int n, const double pose7[7],
+                                     msfl_point* out, int capacity, int* n_out, msfl_mem mem);
+
+msfl_status msfl_grid_size(msfl_grid* g, int* n_points, int* n_cells);
+/* all points, cells ascending (the reference dumps the map to PLY on shutdown, laser_mapping.cc:95-113) */
+msfl_status msfl_grid_dump(msfl_grid* g, msfl_point* out, int capacity, int* n_out, msfl_mem mem);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -21,6 +21,7 @@ EXPORTED = [
     "msfl_associate_scan2map", "msfl_solve_records",
     "msfl_match_scan2scan", "msfl_match_scan2scan_batch", "msfl_extract_features",
     "msfl_extract_features_batch", "msfl_voxel_downsample",
+    "msfl_grid_create", "msfl_grid_destroy", "msfl_grid_insert_scan", "msfl_grid_get_surrounded", "msfl_grid_size", "msfl_grid_dump",
 ]
 
 
@@ -351,4 +352,60 @@ class Handle:
         n_out = C.c_int(0)
         self._check(self.lib.msfl_voxel_downsample(self.h, _vp(pts), C.c_int(len(pts)), C.c_float(leaf), _vp(out),
                                                    C.byref(n_out), C.c_int(MEM_HOST)), "msfl_voxel_downsample")
+        return out[:n_out.value].copy()
+
+
+class Grid:
+    """Device-resident local map store (HybridGrid): msfl_grid_* over a Handle's stream."""
+
+    def __init__(self, handle, resolution=3.0, leaf=0.2):
+        self.handle = handle
+        self.lib = handle.lib
+        self.g = C.c_void_p()
+        handle._check(self.lib.msfl_grid_create(handle.h, C.c_float(resolution), C.c_float(leaf), C.byref(self.g)), "msfl_grid_create")
+
+    def close(self):
+        if self.g:
+            self.lib.msfl_grid_destroy(self.g)
+            self.g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def insert_scan(self, pts, allow=()):
+        pts = _pts(pts)
+        return self.handle._check(self.lib.msfl_grid_insert_scan(self.g, _vp(pts), C.c_int(len(pts)), C.c_int(MEM_HOST)),
+                                  "msfl_grid_insert_scan", allow)
+
+    def size(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self.handle._check(self.lib.msfl_grid_size(self.g, C.byref(a), C.byref(b)), "msfl_grid_size")
+        return a.value, b.value
+
+    def get_surrounded(self, scan, pose):
+        scan = _pts(scan)
+        cap = max(self.size()[0], 1)
+        out = np.zeros((cap, 4), np.float32)
+        n_out = C.c_int(0)
+        pose = np.ascontiguousarray(pose, dtype=np.float64)
+        self.handle._check(self.lib.msfl_grid_get_surrounded(self.g, _vp(scan), C.c_int(len(scan)), _vp(pose), _vp(out), C.c_int(cap),
+                                                             C.byref(n_out), C.c_int(MEM_HOST)), "msfl_grid_get_surrounded")
+        return out[:n_out.value].copy()
+
+    def get_surrounded_device(self, scan_ptr, n, pose, out_ptr, capacity):
+        """Device-resident variant: returns the number of points written at out_ptr."""
+        n_out = C.c_int(0)
+        pose = np.ascontiguousarray(pose, dtype=np.float64)
+        self.handle._check(self.lib.msfl_grid_get_surrounded(self.g, _vp(scan_ptr), C.c_int(n), _vp(pose), _vp(out_ptr), C.c_int(capacity),
+                                                             C.byref(n_out), C.c_int(MEM_DEVICE)), "msfl_grid_get_surrounded(device)")
+        return n_out.value
+
+    def dump(self):
+        cap = max(self.size()[0], 1)
+        out = np.zeros((cap, 4), np.float32)
+        n_out = C.c_int(0)
+        self.handle._check(self.lib.msfl_grid_dump(self.g, _vp(out), C.c_int(cap), C.byref(n_out), C.c_int(MEM_HOST)), "msfl_grid_dump")
         return out[:n_out.value].copy()

@@ -19,6 +19,7 @@
 #include "msfl_kernels.cuh"
 #include "msfl_extract.cuh"
 #include "msfl_odom.cuh"
+#include "msfl_grid.cuh"
 
 using namespace msfl;
 
@@ -691,3 +692,4 @@ msfl_status msfl_solve_records(msfl_handle* h, const msfl_point* corner, int n_c
 }  // extern "C"
 
 #include "msfl_api_stage_ab.inc"
+#include "msfl_api_grid.inc"

@@ -1197,3 +1197,140 @@ int orc_voxel_grid(const orc_point* pts, int n, float leaf, orc_point* out) {
   free(keys);
   return m;
 }
+
+/* =============================================================================================
+ * N1: HybridGrid local map store  (src/slam/map/hybrid_grid.cc:413-534)
+ * ============================================================================================= */
+
+typedef struct { int ix, iy, iz; orc_point* pts; int n, cap; } grid_cell;
+struct orc_grid {
+  float resolution, leaf;
+  grid_cell* cells; int n_cells, cap_cells;     /* kept sorted by (iz, iy, ix) */
+};
+
+orc_grid* orc_grid_create(float resolution, float leaf) {
+  orc_grid* g = (orc_grid*)calloc(1, sizeof(orc_grid));
+  g->resolution = resolution; g->leaf = leaf;
+  return g;
+}
+void orc_grid_free(orc_grid* g) {
+  if (!g) return;
+  for (int i = 0; i < g->n_cells; i++) free(g->cells[i].pts);
+  free(g->cells); free(g);
+}
+static int cell_cmp3(int az, int ay, int ax, const grid_cell* c) {
+  if (az != c->iz) return az < c->iz ? -1 : 1;
+  if (ay != c->iy) return ay < c->iy ? -1 : 1;
+  if (ax != c->ix) return ax < c->ix ? -1 : 1;
+  return 0;
+}
+/* lower bound; *found = 1 if present */
+static int grid_find(const orc_grid* g, int ix, int iy, int iz, int* found) {
+  int lo = 0, hi = g->n_cells;
+  while (lo < hi) {
+    int mid = (lo + hi) / 2;
+    int c = cell_cmp3(iz, iy, ix, &g->cells[mid]);
+    if (c == 0) { *found = 1; return mid; }
+    if (c < 0) hi = mid; else lo = mid + 1;
+  }
+  *found = 0;
+  return lo;
+}
+/* HybridGridBase::GetCellIndex (:422-426): lround(double(p / resolution)) per axis, division in f32 */
+static void grid_cell_index(float resolution, float x, float y, float z, int idx[3]) {
+  idx[0] = (int)lround((double)(x / resolution));
+  idx[1] = (int)lround((double)(y / resolution));
+  idx[2] = (int)lround((double)(z / resolution));
+}
+
+int orc_grid_insert_scan(orc_grid* g, const orc_point* pts, int n) {
+  if (n <= 0) return 0;                                            /* :504 */
+  int* touched = (int*)malloc(sizeof(int) * (size_t)n);
+  int nt = 0;
+  for (int i = 0; i < n; i++) {                                    /* :506-511 */
+    int id[3];
+    grid_cell_index(g->resolution, pts[i].x, pts[i].y, pts[i].z, id);
+    if (abs(id[0]) > 8191 || abs(id[1]) > 8191 || abs(id[2]) > 8191) { free(touched); return 7; }
+    int found, pos = grid_find(g, id[0], id[1], id[2], &found);
+    if (!found) {
+      if (g->n_cells == g->cap_cells) {
+        g->cap_cells = g->cap_cells ? 2 * g->cap_cells : 256;
+        g->cells = (grid_cell*)realloc(g->cells, sizeof(grid_cell) * (size_t)g->cap_cells);
+      }
+      memmove(&g->cells[pos + 1], &g->cells[pos], sizeof(grid_cell) * (size_t)(g->n_cells - pos));
+      g->cells[pos].ix = id[0]; g->cells[pos].iy = id[1]; g->cells[pos].iz = id[2];
+      g->cells[pos].pts = NULL; g->cells[pos].n = 0; g->cells[pos].cap = 0;
+      g->n_cells++;
+    }
+    grid_cell* c = &g->cells[pos];
+    if (c->n == c->cap) { c->cap = c->cap ? 2 * c->cap : 16; c->pts = (orc_point*)realloc(c->pts, sizeof(orc_point) * (size_t)c->cap); }
+    c->pts[c->n++] = pts[i];
+  }
+  /* down-sample every touched cell in place (:513-520) */
+  for (int i = 0; i < n; i++) {
+    int id[3];
+    grid_cell_index(g->resolution, pts[i].x, pts[i].y, pts[i].z, id);
+    int found, pos = grid_find(g, id[0], id[1], id[2], &found);
+    (void)found;
+    touched[nt++] = pos;
+  }
+  for (int t = 0; t < nt; t++) {
+    grid_cell* c = &g->cells[touched[t]];
+    if (c->cap < 0) continue;          /* already filtered in this call */
+    orc_point* tmp = (orc_point*)malloc(sizeof(orc_point) * (size_t)(c->n > 0 ? c->n : 1));
+    int m = orc_voxel_grid(c->pts, c->n, g->leaf, tmp);
+    memcpy(c->pts, tmp, sizeof(orc_point) * (size_t)m);
+    c->n = m;
+    free(tmp);
+    c->cap = -c->cap;                  /* mark */
+  }
+  for (int t = 0; t < nt; t++) { grid_cell* c = &g->cells[touched[t]]; if (c->cap < 0) c->cap = -c->cap; }
+  free(touched);
+  return 0;
+}
+
+int orc_grid_get_surrounded(const orc_grid* g, const orc_point* scan, int n, const double pose[7],
+                            orc_point* out, int capacity) {
+  unsigned char* hit = (unsigned char*)calloc((size_t)(g->n_cells > 0 ? g->n_cells : 1), 1);
+  /* pose.cast<float>(): Rigid3f, Quaternionf * Vector3f + translation, all in f32 (:478) */
+  const float qx = (float)pose[3], qy = (float)pose[4], qz = (float)pose[5], qw = (float)pose[6];
+  const float tx = (float)pose[0], ty = (float)pose[1], tz = (float)pose[2];
+  for (int p = 0; p < n; p++) {
+    const float x = scan[p].x, y = scan[p].y, z = scan[p].z;
+    const float nrm = sqrtf(x * x + y * y + z * z);
+    if ((double)nrm > 60.0) continue;                               /* kDist, :474 */
+    /* Eigen _transformVector in f32: uv = 2 (q.vec x v); v + w uv + q.vec x uv */
+    float ux = qy * z - qz * y, uy = qz * x - qx * z, uz = qx * y - qy * x;
+    ux += ux; uy += uy; uz += uz;
+    const float cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
+    const float wx = (x + qw * ux + cx) + tx, wy = (y + qw * uy + cy) + ty, wz = (z + qw * uz + cz) + tz;
+    for (int i = -1; i <= 1; ++i)
+      for (int j = -1; j <= 1; ++j)
+        for (int k = -1; k <= 1; ++k) {
+          int id[3];
+          grid_cell_index(g->resolution, wx + (float)i, wy + (float)j, wz + (float)k, id);   /* :479-480 */
+          int found, pos = grid_find(g, id[0], id[1], id[2], &found);
+          if (found) hit[pos] = 1;                                                           /* TryInsertGrid */
+        }
+  }
+  int m = 0;
+  for (int c = 0; c < g->n_cells; c++) {
+    if (!hit[c]) continue;
+    for (int i = 0; i < g->cells[c].n; i++) { if (m < capacity) out[m] = g->cells[c].pts[i]; m++; }
+  }
+  free(hit);
+  return m;
+}
+
+int orc_grid_size(const orc_grid* g, int* n_cells) {
+  int n = 0;
+  for (int c = 0; c < g->n_cells; c++) n += g->cells[c].n;
+  if (n_cells) *n_cells = g->n_cells;
+  return n;
+}
+int orc_grid_dump(const orc_grid* g, orc_point* out, int capacity) {
+  int m = 0;
+  for (int c = 0; c < g->n_cells; c++)
+    for (int i = 0; i < g->cells[c].n; i++) { if (m < capacity) out[m] = g->cells[c].pts[i]; m++; }
+  return m;
+}

@@ -191,3 +191,27 @@ int orc_voxel_grid(const orc_point* pts, int n, float leaf, orc_point* out);
 }
 #endif
 #endif
+
+/* ---- N1: the local map store, src/slam/map/hybrid_grid.cc:462-534 ------------- */
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct orc_grid orc_grid;
+/* HybridGrid(resolution) + the pcl::VoxelGrid leaf its owner passes to InsertScan
+   (laser_mapping.cc:44-45,60-68: resolution 3.0, leaf 0.2 corner / 0.4 surf). */
+orc_grid* orc_grid_create(float resolution, float leaf);
+void orc_grid_free(orc_grid* g);
+/* HybridGridImpl::InsertScan (:503-521): append each point to the cell round(p / resolution), then
+   VoxelGrid-filter every touched cell in place.  Returns 0, or 7 if a cell index leaves +-8192. */
+int orc_grid_insert_scan(orc_grid* g, const orc_point* pts, int n);
+/* HybridGridImpl::GetSurroundedCloud (:470-501): union of the cells hit by pose_f32 * p + (i,j,k) m,
+   (i,j,k) in {-1,0,1}^3, for scan points with |p| <= 60.  Cells are emitted in ascending
+   (iz, iy, ix) order (the reference iterates a boost::unordered_set of pointers: unspecified). */
+int orc_grid_get_surrounded(const orc_grid* g, const orc_point* scan, int n, const double pose[7],
+                            orc_point* out, int capacity);
+int orc_grid_size(const orc_grid* g, int* n_cells);
+/* all points, cells ascending, in-cell order as stored */
+int orc_grid_dump(const orc_grid* g, orc_point* out, int capacity);
+#ifdef __cplusplus
+}
+#endif

@@ -293,3 +293,42 @@ def voxel_grid(pts, leaf):
     out = np.zeros((max(len(pts), 1), 4), np.float32)
     m = lib().orc_voxel_grid(_p(pts), C.c_int(len(pts)), C.c_float(leaf), _p(out))
     return out[:m].copy()
+
+
+# ---- N1: HybridGrid local map store ---------------------------------------------------------------
+
+class HybridGrid:
+    """Oracle of src/slam/map/hybrid_grid.cc HybridGridImpl (InsertScan / GetSurroundedCloud)."""
+
+    def __init__(self, resolution=3.0, leaf=0.2):
+        lib().orc_grid_create.restype = C.c_void_p
+        self.g = C.c_void_p(lib().orc_grid_create(C.c_float(resolution), C.c_float(leaf)))
+
+    def insert_scan(self, pts):
+        pts = as_points(pts)
+        return lib().orc_grid_insert_scan(self.g, _p(pts), C.c_int(len(pts)))
+
+    def get_surrounded(self, scan, pose):
+        scan = as_points(scan)
+        cap = max(self.size()[0], 1)
+        out = np.zeros((cap, 4), np.float32)
+        m = lib().orc_grid_get_surrounded(self.g, _p(scan), C.c_int(len(scan)), _p(np.ascontiguousarray(pose, dtype=np.float64)),
+                                          _p(out), C.c_int(cap))
+        return out[:m].copy()
+
+    def size(self):
+        nc = C.c_int(0)
+        n = lib().orc_grid_size(self.g, C.byref(nc))
+        return n, nc.value
+
+    def dump(self):
+        n = max(self.size()[0], 1)
+        out = np.zeros((n, 4), np.float32)
+        m = lib().orc_grid_dump(self.g, _p(out), C.c_int(n))
+        return out[:m].copy()
+
+    def __del__(self):
+        try:
+            lib().orc_grid_free(self.g)
+        except Exception:
+            pass

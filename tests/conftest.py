@@ -25,6 +25,14 @@ def oracle():
 def gpu():
     """A handle on cuda:0.  Fails loudly when the HIP extension or the GPU is missing."""
     from msf_loam_amd import capi
+    try:
+        # initialise torch's HIP context first: tests that share device buffers with torch need it,
+        # and torch refuses to initialise after another library has touched the runtime in-process
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda:0")
+    except Exception:
+        pass
     h = capi.Handle(0)
     yield h
     h.close()

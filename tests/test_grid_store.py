@@ -1,0 +1,128 @@
+"""N1: the local map store (HybridGrid, hybrid_grid.cc:462-534).
+CPU: the oracle against an independent numpy formulation.  GPU: msfl_grid_* against the oracle,
+bit for bit (same cell assignment, same voxel order, same f32 accumulation order)."""
+import numpy as np
+import pytest
+
+from msf_loam_amd import synth
+from tests import common
+
+
+def _np_grid(points_batches, resolution, leaf):
+    """Independent formulation: per cell, repeatedly voxel-filter (old centroids + new points)."""
+    cells = {}
+    for pts in points_batches:
+        idx = np.stack([np.round(np.float64(pts[:, a] / np.float32(resolution))) for a in range(3)], axis=1).astype(int)
+        # lround = half away from zero
+        frac = (pts[:, :3] / np.float32(resolution)).astype(np.float64)
+        idx = np.where(np.abs(frac - np.trunc(frac)) == 0.5, np.trunc(frac) + np.sign(frac), np.round(frac)).astype(int)
+        touched = set()
+        for p, c in zip(pts, map(tuple, idx)):
+            cells.setdefault(c, []).append(p)
+            touched.add(c)
+        for c in touched:
+            cells[c] = list(synth.voxel_downsample_np(np.array(cells[c], np.float32), leaf))
+    order = sorted(cells, key=lambda c: (c[2], c[1], c[0]))
+    return np.array([p for c in order for p in cells[c]], np.float32), order
+
+
+def _batches(n_batches=4, seed=3):
+    w, _, _ = common.small_world(20000)
+    poses = synth.random_poses(n_batches, synth.SEED + seed)
+    out = []
+    for i in range(n_batches):
+        pts, ring = synth.make_scan(w, poses[i], synth.SEED + 50 + i, n_az=600)
+        world_pts = pts.copy()
+        world_pts[:, :3] = (pts[:, :3].astype(np.float64) @ synth.quat_to_matrix(poses[i][3:]).T + poses[i][:3]).astype(np.float32)
+        world_pts[:, 3] = np.linspace(0, 0.1, len(pts), dtype=np.float32)
+        out.append((pts, world_pts, poses[i]))
+    return out
+
+
+def test_oracle_grid_matches_numpy_formulation(oracle):
+    g = oracle.HybridGrid(3.0, 0.4)
+    bs = _batches()
+    for _, wp, _ in bs:
+        assert g.insert_scan(wp) == 0
+    want, order = _np_grid([wp for _, wp, _ in bs], 3.0, 0.4)
+    got = g.dump()
+    assert got.shape == want.shape and g.size() == (len(want), len(order))
+    assert np.allclose(got, want, atol=2e-5)                 # f32 vs f64 centroid accumulation
+    # re-inserting nothing changes nothing; filtering is idempotent
+    g.insert_scan(np.zeros((0, 4), np.float32))
+    assert np.array_equal(g.dump(), got)
+    # surrounded cloud: subset of the map, whole cells, includes the cell under the sensor
+    scan, _, pose = bs[0]
+    s = g.get_surrounded(scan, pose)
+    assert 0 < len(s) <= len(got)
+    cell = lambda p: tuple(np.round(p[:3] / 3.0).astype(int))
+    assert cell(np.r_[pose[:3]]) in {cell(p) for p in s[::7]} or len(s) > 1000
+    # out of range -> 7, cells at half-integer boundaries round away from zero
+    assert oracle.HybridGrid(3.0, 0.4).insert_scan(np.array([[3e4, 0, 0, 0]], np.float32)) == 7
+    g2 = oracle.HybridGrid(3.0, 0.4)
+    g2.insert_scan(np.array([[1.5, -1.5, 4.5, 0], [1.4999, -1.4999, 0, 0]], np.float32))
+    assert g2.size()[1] == 2
+
+
+@pytest.mark.gpu
+def test_gpu_grid_matches_oracle_bit_for_bit(gpu, oracle):
+    from msf_loam_amd import capi
+    for leaf in (0.2, 0.4):
+        go, gg = oracle.HybridGrid(3.0, leaf), capi.Grid(gpu, 3.0, leaf)
+        bs = _batches()
+        for k, (scan, wp, pose) in enumerate(bs):
+            assert go.insert_scan(wp) == 0
+            gg.insert_scan(wp)
+            assert gg.size() == go.size()
+            assert np.array_equal(gg.dump(), go.dump()), (leaf, k)
+            for sc, ps in ((scan, pose), (bs[0][0], bs[0][2])):
+                a, b = gg.get_surrounded(sc, ps), go.get_surrounded(sc, ps)
+                assert np.array_equal(a, b)
+        # far scan: nothing around it
+        far = bs[0][0].copy(); far[:, :3] *= 0.01
+        assert len(gg.get_surrounded(far, np.array([5e3, 0, 0, 0, 0, 0, 1.0]))) == 0
+        # out-of-range point: MSFL_CAPACITY and the map is untouched
+        before = gg.dump()
+        assert gg.insert_scan(np.array([[3e4, 0, 0, 0]], np.float32), allow=(capi.CAPACITY,)) == capi.CAPACITY
+        assert np.array_equal(gg.dump(), before)
+        gg.close()
+
+
+@pytest.mark.gpu
+def test_surrounded_cloud_feeds_set_map_on_device(gpu, oracle):
+    """insert -> get_surrounded (device) -> msfl_set_map (device) -> match: the mapping loop without
+    the map ever leaving the GPU, against the oracle doing the same through host arrays."""
+    import torch
+    from msf_loam_amd import capi
+    w, _, _ = common.small_world(20000)
+    grids = {k: (capi.Grid(gpu, 3.0, leaf), oracle.HybridGrid(3.0, leaf)) for k, leaf in (("c", 0.2), ("s", 0.4))}
+    poses = synth.random_poses(6, synth.SEED + 7)
+    feats = []
+    for i in range(6):
+        pts, ring = synth.make_scan(w, poses[i], synth.SEED + 70 + i)
+        f = oracle.extract_features(pts, ring)
+        feats.append(f)
+        for k, key in (("c", "less_sharp"), ("s", "less_flat")):
+            cloud = oracle.voxel_grid(f["full"][f[key]], 0.2 if k == "c" else 0.4)
+            wp = cloud.copy()
+            wp[:, :3] = (cloud[:, :3].astype(np.float64) @ synth.quat_to_matrix(poses[i][3:]).T + poses[i][:3]).astype(np.float32)
+            grids[k][0].insert_scan(wp); grids[k][1].insert_scan(wp)
+    f = feats[2]
+    guess = synth.perturb_pose(poses[2], np.random.default_rng(1), 0.1, 1.0)
+    dev = torch.device("cuda", 0)
+    maps = {}
+    for k, key in (("c", "less_sharp"), ("s", "less_flat")):
+        scan = torch.from_numpy(np.ascontiguousarray(f["full"][f[key]])).to(dev)
+        cap = grids[k][0].size()[0]
+        out = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        n = grids[k][0].get_surrounded_device(scan, len(scan), guess, out, cap)
+        maps[k] = (out, n, grids[k][1].get_surrounded(f["full"][f[key]], guess))
+        assert n == len(maps[k][2]) and np.array_equal(out[:n].cpu().numpy(), maps[k][2])
+    gpu.set_map(maps["c"][0], maps["s"][0], maps["c"][1], maps["s"][1], capi.MEM_DEVICE)
+    corner, surf = oracle.voxel_grid(f["full"][f["less_sharp"]], 0.2), oracle.voxel_grid(f["full"][f["less_flat"]], 0.4)
+    s, pg, _ = gpu.match_scan2map(corner, surf, guess)
+    rc, po, _ = oracle.match_scan2map(maps["c"][2], maps["s"][2], corner, surf, guess)
+    assert s == rc == 0 and max(synth.pose_error(pg, po)) < 1e-7
+    for k in grids:
+        grids[k][0].close()
