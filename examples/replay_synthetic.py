@@ -7,9 +7,10 @@ laser_mapping.cc:138-258), LiDAR-only:
     extract features (stage A) -> MatchScan2Scan against the previous scan (stage B)
     -> pose_odom chain -> voxel down-sample (0.2 / 0.4 m) -> MatchScan2Map against the accumulated
     map (stage C) -> TransformUpdate -> insert the scan's features into the map.
-The map store here is a plain voxel-centroid union kept by the harness (the reference's HybridGrid
-is outside the path).  `backend` is either the GPU library or, in tests, the CPU
-oracle driven through the same loop, so the two trajectories can be compared pose by pose.
+The map store is the device-resident HybridGrid replacement (msfl_grid_*):
+InsertScan2Map / GetSurroundedCloud as in laser_mapping.cc:273-278,330-338.  `backend` is either the
+GPU library or, in tests, the CPU oracle driven through the same loop, so the two trajectories can
+be compared pose by pose.
 """
 import argparse
 import json
@@ -77,15 +78,18 @@ class GpuBackend:
         s, p, _ = self.mapper.match_scan2map(corner, surf, pose)
         return p
 
+    def new_grids(self):
+        return self.capi.Grid(self.mapper, 3.0, 0.2), self.capi.Grid(self.mapper, 3.0, 0.4)   # laser_mapping.cc:44-45,60-68
+
 
 def run(backend, world, poses_true, verbose=False):
     n = len(poses_true)
     odo2first = np.array([0, 0, 0, 0, 0, 0, 1.0])        # pose_scan2world_ (odometry frame = first scan)
     curr2last = np.array([0, 0, 0, 0, 0, 0, 1.0])
     odom2map = poses_true[0].copy()                       # anchor the map frame at the true first pose
-    map_c = np.zeros((0, 4), np.float32); map_s = np.zeros((0, 4), np.float32)
+    grid_c, grid_s = backend.new_grids()                  # hybrid_grid_map_corner_ / hybrid_grid_map_surf_
     last = None
-    est, t_stage = [], dict(extract=0.0, odometry=0.0, voxel=0.0, mapping=0.0)
+    est, t_stage = [], dict(extract=0.0, odometry=0.0, voxel=0.0, surround=0.0, mapping=0.0, insert=0.0)
     for k in range(n):
         pts, ring = synth.make_scan(world, poses_true[k], synth.SEED + 5000 + k)
         t0 = time.perf_counter(); f = backend.extract(pts, ring); t1 = time.perf_counter()
@@ -97,19 +101,24 @@ def run(backend, world, poses_true, verbose=False):
         surf = backend.voxel(f["full"][f["less_flat"]], 0.4)
         t3 = time.perf_counter()
         pose_map = compose(odom2map, odo2first)                               # TransformAssociateToMap, laser_mapping.h:55-57
+        map_c = grid_c.get_surrounded(f["full"][f["less_sharp"]], pose_map)   # GetSurroundedCloud on the UN-down-sampled
+        map_s = grid_s.get_surrounded(f["full"][f["less_flat"]], pose_map)    # feature clouds, laser_mapping.cc:273-278
+        t3b = time.perf_counter()
         if len(map_c) > 10 and len(map_s) > 50:                               # gate, laser_mapping.cc:284-285
             pose_map = backend.scan2map(map_c, map_s, corner, surf, pose_map)
         t4 = time.perf_counter()
         odom2map = compose(pose_map, inverse(odo2first))                      # TransformUpdate, laser_mapping.h:59-61
-        map_c = synth.voxel_downsample_np(np.concatenate([map_c, transform_cloud(pose_map, corner)]), 0.2)   # InsertScan2Map
-        map_s = synth.voxel_downsample_np(np.concatenate([map_s, transform_cloud(pose_map, surf)]), 0.4)
+        grid_c.insert_scan(transform_cloud(pose_map, f["full"][f["less_sharp"]]))   # InsertScan2Map, laser_mapping.cc:330-338
+        grid_s.insert_scan(transform_cloud(pose_map, f["full"][f["less_flat"]]))
+        t5 = time.perf_counter()
         last = f
         est.append(pose_map)
-        for name, dt in (("extract", t1 - t0), ("odometry", t2 - t1), ("voxel", t3 - t2), ("mapping", t4 - t3)):
+        for name, dt in (("extract", t1 - t0), ("odometry", t2 - t1), ("voxel", t3 - t2), ("surround", t3b - t3),
+                         ("mapping", t4 - t3b), ("insert", t5 - t4)):
             if k >= 2:
                 t_stage[name] += dt
         if verbose and k % 20 == 0:
-            print(k, synth.pose_error(pose_map, poses_true[k]), len(map_c), len(map_s), file=sys.stderr)
+            print(k, synth.pose_error(pose_map, poses_true[k]), grid_c.size(), grid_s.size(), file=sys.stderr)
     m = max(n - 2, 1)
     return np.array(est), {k: 1e3 * v / m for k, v in t_stage.items()}
 
