@@ -5,6 +5,7 @@
 //   msfl::OdometryScanMatcher::MatchScan2Scan   <- src/slam/local/scan_matching/odometry_scan_matcher.h:10-12
 //   msfl::MappingScanMatcher::MatchScan2Map     <- src/slam/local/scan_matching/mapping_scan_matcher.h:14-21
 //   msfl::ScanRegistration::Extract             <- RealHandleLaserCloudMessage, src/msf_loam_node.cc:160-378
+//   msfl::HybridGrid::{GetSurroundedCloud,InsertScan} <- src/slam/map/hybrid_grid.h:27-39 (next row N1)
 //   msfl::Rigid3d                               <- src/common/rigid_transform.h:36-128
 //   msfl::TimestampedPointCloud<T>              <- src/common/timestamped_pointcloud.h:11-42
 //   msfl::PointXYZI / PointXYZIRT               <- pcl::PointXYZI / src/common/common.h:44-62
@@ -247,6 +248,46 @@ class ScanRegistration {
  private:
   msfl_handle* h_ = nullptr;
   Rigid3d lidar2imu_;
+};
+
+// HybridGrid (src/slam/map/hybrid_grid.h:27-39): the local map store, resident on the device.
+// The reference passes the pcl::VoxelGrid filter to InsertScan; here its leaf is fixed at
+// construction (laser_mapping.cc:60-68 uses one leaf per map for the whole run).
+class HybridGrid {
+ public:
+  HybridGrid(const float& resolution, float voxel_leaf, int device = 0) {
+    detail::Check(msfl_create(nullptr, device, &h_), nullptr, "msfl_create");
+    detail::Check(msfl_grid_create(h_, resolution, voxel_leaf, &g_), h_, "msfl_grid_create");
+  }
+  virtual ~HybridGrid() { msfl_grid_destroy(g_); msfl_destroy(h_); }
+  HybridGrid(const HybridGrid&) = delete;
+  HybridGrid& operator=(const HybridGrid&) = delete;
+
+  std::shared_ptr<PointCloud<PointType>> GetSurroundedCloud(const std::shared_ptr<const PointCloud<PointType>>& scan,
+                                                            const Rigid3d& pose) {
+    const std::vector<msfl_point> in = detail::Pack(*scan);
+    int n_pts = 0, n_cells = 0;
+    detail::Check(msfl_grid_size(g_, &n_pts, &n_cells), h_, "msfl_grid_size");
+    std::vector<msfl_point> out(static_cast<std::size_t>(n_pts > 0 ? n_pts : 1));
+    int n_out = 0;
+    const auto v = pose.ToVector7();
+    detail::Check(msfl_grid_get_surrounded(g_, in.data(), static_cast<int>(in.size()), v.data(), out.data(), n_pts, &n_out,
+                                           MSFL_MEM_HOST), h_, "msfl_grid_get_surrounded");
+    auto cloud = std::make_shared<PointCloud<PointType>>();
+    cloud->points.reserve(static_cast<std::size_t>(n_out));
+    for (int i = 0; i < n_out; ++i) cloud->push_back({out[i].x, out[i].y, out[i].z, out[i].t});
+    return cloud;
+  }
+
+  void InsertScan(const std::shared_ptr<PointCloud<PointType>>& scan) {
+    if (scan->empty()) return;                                        // hybrid_grid.cc:504
+    const std::vector<msfl_point> in = detail::Pack(*scan);
+    detail::Check(msfl_grid_insert_scan(g_, in.data(), static_cast<int>(in.size()), MSFL_MEM_HOST), h_, "msfl_grid_insert_scan");
+  }
+
+ private:
+  msfl_handle* h_ = nullptr;
+  msfl_grid* g_ = nullptr;
 };
 
 }  // namespace msfl
