@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsfl_hip.so")
+# MSFL_LIB: load another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("MSFL_LIB") or os.path.join(_HERE, "libmsfl_hip.so")
 
 OK, TOO_FEW_CORRESPONDENCES, MAP_TOO_SMALL, BAD_ARG, HIP_ERROR, BAD_RING, NO_MAP, CAPACITY = range(8)
 MEM_HOST, MEM_DEVICE = 0, 1

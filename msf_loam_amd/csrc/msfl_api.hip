@@ -104,6 +104,7 @@ struct msfl_handle_s {
   bool have_map = false;
   MapIndex map_c, map_s;
   int grid_cap_cells = 64 * 1024 * 1024;  // hard limit of the dense cell table (MSFL_GRID_CAP_CELLS)
+  bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)
 
   // scratch
   DevBuf in_corner, in_surf, in_off, poses, status, info, records, pprime, nn;
@@ -404,6 +405,7 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
   }
   h->stream = h->own_stream;
   if (const char* e = std::getenv("MSFL_GRID_CAP_CELLS")) { const int c = std::atoi(e); if (c >= 8 && c <= (1 << 28)) h->grid_cap_cells = c; }
+  if (const char* e = std::getenv("MSFL_ODOM_BRUTE")) h->odom_force_brute = std::atoi(e) != 0;
   *out = h;
   return MSFL_OK;
 }

@@ -38,7 +38,7 @@ __device__ __forceinline__ float odom_dist(float4 a, float3 q) {
 // bv.corner = curr sharp, bv.surf = curr flat; records in feature order (sharp first).
 __global__ void __launch_bounds__(256)
 assoc_scan2scan_kernel(BatchView bv, OdomView ov, const double* __restrict__ poses, const int* __restrict__ status,
-                       double* __restrict__ rec) {
+                       double* __restrict__ rec, const int* __restrict__ plane_mode) {
   __shared__ float4 s_tile[kOdomTile];
   const int b = blockIdx.y;
   const int n_sharp = bv.corner_off[b + 1] - bv.corner_off[b];
@@ -55,8 +55,10 @@ assoc_scan2scan_kernel(BatchView bv, OdomView ov, const double* __restrict__ pos
     if (has_q) for (int k = 0; k < out_len; k++) out[k] = 0.0;
     return;
   }
+  // plane_mode[b] == 0: the column-grid kernel below owns this pair's plane queries
+  const bool planes_here = plane_mode == nullptr || plane_mode[b] != 0;
   const bool is_edge = has_q && qi < n_sharp;
-  const bool is_plane = has_q && !is_edge;
+  const bool is_plane = has_q && !is_edge && planes_here;
   float4 f = make_float4(0, 0, 0, 0);
   float3 q = make_float3(0, 0, 0);
   if (has_q) {
@@ -67,7 +69,7 @@ assoc_scan2scan_kernel(BatchView bv, OdomView ov, const double* __restrict__ pos
   const float thr = (float)ov.dist_sq_threshold;
   // which target clouds does this workgroup need? (uniform)
   const bool wg_has_edge = q0 < n_sharp;
-  const bool wg_has_plane = (q0 + 256 > n_sharp) && (nq > n_sharp);
+  const bool wg_has_plane = (q0 + 256 > n_sharp) && (nq > n_sharp) && planes_here;
   int closest = -1, min2 = -1, min3 = -1;
 
   for (int which = 0; which < 2; which++) {
@@ -294,6 +296,226 @@ assoc_scan2scan_wave_kernel(BatchView bv, OdomView ov, const double* __restrict_
     }
     out[0] = N.x; out[1] = N.y; out[2] = N.z; out[3] = dot(N, C);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Throughput path for the plane queries (384 flat features x ~20 k less-flat targets per pair is
+// >95 % of the brute-force work).  The previous scans' less-flat clouds are bucketed into a
+// 1 m x-y column grid — one radix sort over the whole batch with key (pair | cy | cx), so every
+// pair keeps its own contiguous segment and a row of x-adjacent columns is one contiguous run —
+// and each query walks the 3x3, 5x5 and 13x13 column neighbourhoods until the exact lower bound
+// of everything outside the walked square exceeds what it has found.
+//
+// The ring-window scans (:183-232) are index-ordered sweeps with `break`; on a cloud whose rings
+// are non-decreasing in array order (what scan registration produces, msf_loam_node.cc:243-356)
+// they select exactly {j > closest, ring <= id + 2.5} and {j < closest, ring >= id - 2.5}, and the
+// running strict '<' minima become lexicographic minima over (distance, index).  Pairs whose
+// cloud is not ring-monotone, has a ring >= 256, a point outside +-512 m or a non-finite
+// coordinate keep the brute-force kernel above (mode[b] = 1); results are identical either way.
+// ---------------------------------------------------------------------------------------------
+constexpr int kOdomCellBits = 10;                       // 1 m columns, +-512 m
+constexpr int kOdomCellOff = 1 << (kOdomCellBits - 1);
+constexpr int kOdomPairBits = 32 - 2 * kOdomCellBits;   // pairs per sort chunk (4096)
+#ifndef MSFL_ODOM_LANES
+#define MSFL_ODOM_LANES 16
+#endif
+constexpr int kOdomLanes = MSFL_ODOM_LANES;             // lanes cooperating on one plane query
+constexpr int kOdomMaxLevel = 6;                        // gap >= 6 m  >  sqrt(25): nothing outside can pass the 25 m^2 gate
+
+__device__ __forceinline__ int odom_find_pair(const int* __restrict__ off, int B, int i) {
+  int lo = 0, hi = B;                                   // largest b with off[b] <= i
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
+  return lo;
+}
+
+// key per less-flat target; pairs [b0, b0 + nb) form one sort chunk
+__global__ void __launch_bounds__(256)
+odom_key_kernel(const float4* __restrict__ pts, const uint16_t* __restrict__ ring, const int* __restrict__ off, int B, int b0, int nb,
+                unsigned* __restrict__ keys, unsigned* __restrict__ vals, int* __restrict__ mode) {
+  const int base = off[b0];
+  const int n = off[b0 + nb] - base;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int i = base + t;
+  const int b = b0 + odom_find_pair(off + b0, nb, i);
+  const float4 p = pts[i];
+  const int j = i - off[b];
+  const int r = ring[i];
+  bool bad = !(fabsf(p.x) < (float)kOdomCellOff && fabsf(p.y) < (float)kOdomCellOff && fabsf(p.z) < 1e30f) || r >= 256 || j >= (1 << 24);
+  if (j > 0 && ring[i - 1] > r) bad = true;
+  unsigned key = (unsigned)(b - b0) << (2 * kOdomCellBits);
+  if (!bad) key |= ((unsigned)((int)floorf(p.y) + kOdomCellOff) << kOdomCellBits) | (unsigned)((int)floorf(p.x) + kOdomCellOff);
+  else mode[b] = 1;
+  keys[i] = key;
+  vals[i] = (unsigned)i;
+}
+
+// sorted target record: xyz + (ring << 24 | index within the pair's cloud)
+__global__ void __launch_bounds__(256)
+odom_gather_kernel(const float4* __restrict__ pts, const uint16_t* __restrict__ ring, const int* __restrict__ off, int b0,
+                   const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, int first, int n, float4* __restrict__ sorted) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int i = first + t;
+  const int src = (int)vals[i];
+  const int b = b0 + (int)(keys[i] >> (2 * kOdomCellBits));
+  float4 p = pts[src];
+  p.w = __int_as_float((int)(((unsigned)ring[src] & 0xffu) << 24 | (unsigned)(src - off[b])));
+  sorted[i] = p;
+}
+
+struct OdomIndex {
+  const unsigned* keys;      // sorted, aligned with `sorted`
+  const float4* sorted;
+  const int* mode;           // per pair: 0 = column grid, 1 = brute force
+  int chunk;                 // pairs per sort chunk; a key's pair field is b % chunk
+};
+
+__device__ __forceinline__ int odom_lower_bound(const unsigned* __restrict__ keys, int lo, int hi, unsigned key) {
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// L lanes (a power of two, one query per L-lane group) walk the (2r+1)^2 column square around
+// (cx, cy) of the pair segment [s0, s1): the 2 x rows run boundaries are binary-searched one per
+// lane, then every row's run is read L targets at a time (coalesced); f(float4) per target.
+template <int L, class F>
+__device__ __forceinline__ void odom_walk(const OdomIndex& ix, unsigned pair_bits, int s0, int s1, int cx, int cy, int r, int sl, F&& f) {
+  const int lim = (1 << kOdomCellBits) - 1;
+  const int x0 = max(cx - r, 0), x1 = min(cx + r, lim);
+  const int y0 = max(cy - r, 0), y1 = min(cy + r, lim);
+  if (x0 > x1 || y0 > y1) return;
+  const int n_search = 2 * (y1 - y0 + 1);                  // <= 26
+  constexpr int kRounds = (2 * (2 * kOdomMaxLevel + 1) + L - 1) / L;
+  int res[kRounds];
+#pragma unroll
+  for (int k = 0; k < kRounds; k++) {
+    const int sidx = k * L + sl;
+    res[k] = s1;
+    if (sidx < n_search) {
+      const unsigned row = pair_bits | ((unsigned)(y0 + (sidx >> 1)) << kOdomCellBits);
+      // run of the row = [lower_bound(row | x0), lower_bound(row | x1 + 1)); x1 + 1 may carry into the y field: still the right bound
+      res[k] = odom_lower_bound(ix.keys, s0, s1, (sidx & 1) ? row + (unsigned)x1 + 1u : row | (unsigned)x0);
+    }
+  }
+  for (int row = 0; row <= y1 - y0; row++) {
+    int b0 = 0, b1 = 0;
+#pragma unroll
+    for (int k = 0; k < kRounds; k++) {
+      const int v0 = __shfl(res[k], (2 * row) % L, L), v1 = __shfl(res[k], (2 * row + 1) % L, L);
+      if ((2 * row) / L == k) b0 = v0;
+      if ((2 * row + 1) / L == k) b1 = v1;
+    }
+    for (int i = b0 + sl; i < b1; i += L) f(ix.sorted[i]);
+  }
+}
+
+// exact lower bound (squared, with a 1e-4 safety factor >> f32 rounding) on the distance from q to
+// any target outside the walked square of half-width r columns
+__device__ __forceinline__ float odom_gap_sq(float3 q, float fx, float fy, int r) {
+  const float g = fminf(fminf(q.x - (fx - (float)r), (fx + 1.f + (float)r) - q.x), fminf(q.y - (fy - (float)r), (fy + 1.f + (float)r) - q.y));
+  return g * g * 0.9999f;
+}
+
+template <int L>
+__device__ __forceinline__ void group_min_lo(float& d, int& j) {      // min distance, ties -> smallest j
+#pragma unroll
+  for (int o = L / 2; o > 0; o >>= 1) {
+    const float d2 = __shfl_xor(d, o); const int j2 = __shfl_xor(j, o);
+    if (d2 < d || (d2 == d && j2 < j)) { d = d2; j = j2; }
+  }
+}
+template <int L>
+__device__ __forceinline__ void group_min_hi(float& d, int& j) {      // min distance, ties -> largest j (-1 = none)
+#pragma unroll
+  for (int o = L / 2; o > 0; o >>= 1) {
+    const float d2 = __shfl_xor(d, o); const int j2 = __shfl_xor(j, o);
+    if (d2 < d || (d2 == d && j2 > j)) { d = d2; j = j2; }
+  }
+}
+
+template <int L>
+__global__ void __launch_bounds__(256)
+assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const double* __restrict__ poses,
+                                  const int* __restrict__ status, double* __restrict__ rec) {
+  const int b = blockIdx.x;
+  if (ix.mode[b] != 0) return;                                   // brute-force kernel owns this pair
+  const int n_sharp = bv.corner_off[b + 1] - bv.corner_off[b];
+  const int n_flat = bv.surf_off[b + 1] - bv.surf_off[b];
+  const int sl = threadIdx.x % L;
+  const int qf = blockIdx.y * (256 / L) + threadIdx.x / L;
+  if (qf >= n_flat) return;
+  double* out = rec + rec_base(bv, b) + 6 * (size_t)n_sharp + 4 * (size_t)qf;
+  const int s0 = ov.last_lf_off[b], s1 = ov.last_lf_off[b + 1];
+  const float4* tp = ov.last_lf + s0;
+  const float thr = (float)ov.dist_sq_threshold;
+  bool ok = status[b] == 0 && s1 > s0;
+  float3 q = make_float3(0, 0, 0);
+  if (ok) {
+    const float4 f = bv.surf[bv.surf_off[b] + qf];
+    q = transform_point_f32(load_pose(poses + 7 * b), f.x, f.y, f.z);
+    ok = fabsf(q.x) < (float)(kOdomCellOff + kOdomMaxLevel + 1) && fabsf(q.y) < (float)(kOdomCellOff + kOdomMaxLevel + 1);   // also rejects NaN
+  }
+  if (!ok) { if (sl < 4) out[sl] = 0.0; return; }
+  const float fx = floorf(q.x), fy = floorf(q.y);
+  const int cx = (int)fx + kOdomCellOff, cy = (int)fy + kOdomCellOff;
+  const unsigned pair_bits = (unsigned)(b % ix.chunk) << (2 * kOdomCellBits);
+  // ---- exact 1-NN (:169), ties -> lower index; w = ring << 24 | index, so (d, w & 0xffffff) orders candidates ----
+  float best = INFINITY; int bw = 0x7fffffff;
+  for (int l = 0; l < 3; l++) {
+    const int r = l == 0 ? 1 : l == 1 ? 2 : kOdomMaxLevel;
+    odom_walk<L>(ix, pair_bits, s0, s1, cx, cy, r, sl, [&](const float4 p) {
+      const float d = odom_dist(p, q);
+      const int w = __float_as_int(p.w);
+      if (d < best || (d == best && (w & 0xffffff) < (bw & 0xffffff))) { best = d; bw = w; }
+    });
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) {
+      const float d2 = __shfl_xor(best, o); const int w2 = __shfl_xor(bw, o);
+      if (d2 < best || (d2 == best && (w2 & 0xffffff) < (bw & 0xffffff))) { best = d2; bw = w2; }
+    }
+    if (best < odom_gap_sq(q, fx, fy, r)) break;
+  }
+  if (!(best < thr)) { if (sl < 4) out[sl] = 0.0; return; }       // :173
+  const int closest = bw & 0xffffff, id = (int)((unsigned)bw >> 24);
+  // ---- ring-window minima (:183-232) ----
+  const float hi_ring = (float)id + (float)ov.nearby_scan, lo_ring = (float)id - (float)ov.nearby_scan;
+  float f2, f3, b2, b3;
+  int jf2, jf3, jb2, jb3;
+  for (int l = 0; l < 3; l++) {
+    const int r = l == 0 ? 1 : l == 1 ? 2 : kOdomMaxLevel;
+    f2 = f3 = b2 = b3 = thr; jf2 = jf3 = 0x7fffffff; jb2 = jb3 = -1;      // each level re-walks the inner square too
+    odom_walk<L>(ix, pair_bits, s0, s1, cx, cy, r, sl, [&](const float4 p) {
+      const int w = __float_as_int(p.w), j = w & 0xffffff, rj = (int)((unsigned)w >> 24);
+      if (j == closest || (float)rj > hi_ring || (float)rj < lo_ring) return;
+      const float d = odom_dist(p, q);
+      if (!(d < thr)) return;                                    // every running minimum starts at the 25 m^2 gate
+      if (j > closest) {
+        if (rj <= id) { if (d < f2 || (d == f2 && j < jf2)) { f2 = d; jf2 = j; } }
+        else { if (d < f3 || (d == f3 && j < jf3)) { f3 = d; jf3 = j; } }
+      } else {
+        if (rj >= id) { if (d < b2 || (d == b2 && j > jb2)) { b2 = d; jb2 = j; } }
+        else { if (d < b3 || (d == b3 && j > jb3)) { b3 = d; jb3 = j; } }
+      }
+    });
+    group_min_lo<L>(f2, jf2); group_min_lo<L>(f3, jf3); group_min_hi<L>(b2, jb2); group_min_hi<L>(b3, jb3);
+    const float g = odom_gap_sq(q, fx, fy, r);
+    if (fminf(f2, b2) < g && fminf(f3, b3) < g) break;
+  }
+  if (sl != 0) return;
+  if (jf2 == 0x7fffffff) jf2 = -1;
+  if (jf3 == 0x7fffffff) jf3 = -1;
+  const int min2 = (jb2 >= 0 && b2 < f2) ? jb2 : jf2;           // backward continues the forward minimum with strict '<'
+  const int min3 = (jb3 >= 0 && b3 < f3) ? jb3 : jf3;
+  d3 C = mk3(0, 0, 0), N = mk3(0, 0, 0);
+  if (min2 >= 0 && min3 >= 0) {                                  // :234-256, lidar_factor.h:70-78
+    const float4 a = tp[closest], c = tp[min2], e = tp[min3];
+    const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z),
+             Cp = mk3((double)e.x, (double)e.y, (double)e.z);
+    N = normalized(cross(A - Bp, A - Cp));
+    C = mk3((A.x + Bp.x + Cp.x) / 3, (A.y + Bp.y + Cp.y) / 3, (A.z + Bp.z + Cp.z) / 3);
+  }
+  out[0] = N.x; out[1] = N.y; out[2] = N.z; out[3] = dot(N, C);
 }
 
 }  // namespace msfl

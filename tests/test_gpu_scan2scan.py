@@ -110,3 +110,56 @@ def test_tiled_throughput_kernel_equals_wave_latency_kernel(gpu, oracle):
         assert s == 0 and np.array_equal(p, poses[b]), b
     rc, pose_o, _ = oracle.match_scan2scan(*pairs[7], guesses[7])
     assert max(synth.pose_error(poses[7], pose_o)) < TIGHT
+
+
+def _batch_sets(pairs):
+    sets = []
+    for k in range(4):
+        pick = lambda p: (p[0], p[2], p[4], p[5])[k]
+        pts = np.concatenate([pick(p) for p in pairs])
+        off = np.cumsum([0] + [len(pick(p)) for p in pairs]).astype(np.int32)
+        ring = np.concatenate([(p[1], p[3])[k] for p in pairs]) if k < 2 else None
+        sets.append((pts, ring, off))
+    return sets
+
+
+def test_column_grid_planes_equal_brute_force(gpu, oracle, monkeypatch):
+    """Large batches look plane correspondences up in a per-pair column grid; pairs the grid cannot
+    take (rings not sorted, a point beyond +-512 m) stay on the brute-force kernel inside the same
+    launch.  Every pair must reproduce its single-pair (wave kernel) result bit for bit, also with
+    guesses far enough off that many queries walk the widest neighbourhood or find nothing."""
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    base = [list(_clouds(*_pair(oracle, i))) for i in range(3)]
+    rng = np.random.default_rng(11)
+    shuffled = [np.copy(a) for a in base[1]]
+    perm = np.concatenate([np.sort(b) for b in np.array_split(rng.permutation(len(shuffled[2])), 30)])
+    shuffled[2], shuffled[3] = shuffled[2][perm], shuffled[3][perm]
+    far = [np.copy(a) for a in base[2]]
+    far[2] = np.concatenate([far[2], np.array([[600.0, 3.0, 1.0, 0.0]], np.float32)])
+    far[3] = np.concatenate([far[3], far[3][-1:]])
+    variants = [base[0], base[1], base[2], shuffled, far]
+    pairs = [variants[i % 5] for i in range(45)]
+    guesses = np.stack([ident] * 45)
+    guesses[:, 0] = np.linspace(-2.5, 2.5, 45)               # up to 2.5 m off: sparse matches, wide walks
+    guesses[:, 1] = np.linspace(1.0, -1.0, 45)
+    guesses[44] = np.array([300.0, 0, 0, 0, 0, 0, 1.0])      # nothing within 5 m
+    sets = _batch_sets(pairs)
+    poses, status, info = gpu.match_scan2scan_batch(sets, guesses, want_info=True)
+    assert status[44] == capi.TOO_FEW_CORRESPONDENCES
+    for b in range(45):
+        s, p, i1 = gpu.match_scan2scan(*pairs[b], guesses[b])
+        assert s == status[b], b
+        assert np.array_equal(p, poses[b]), b
+        assert i1.n_plane[0] == info[b].n_plane[0] and i1.n_plane[1] == info[b].n_plane[1], b
+    for b in (0, 3, 4, 22):
+        rc, pose_o, _ = oracle.match_scan2scan(*pairs[b], guesses[b])
+        assert rc == status[b]
+        assert max(synth.pose_error(poses[b], pose_o)) < TIGHT
+    # the same batch with the grid disabled
+    monkeypatch.setenv("MSFL_ODOM_BRUTE", "1")
+    h2 = capi.Handle(0)
+    try:
+        poses2, status2, _ = h2.match_scan2scan_batch(sets, guesses)
+    finally:
+        h2.close()
+    assert np.array_equal(status, status2) and np.array_equal(poses, poses2)

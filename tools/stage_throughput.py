@@ -57,7 +57,8 @@ ident = np.tile([0, 0, 0, 0, 0, 0, 1.0], (B, 1))
 h.set_timing(True); h.get_timing(True)
 for _ in range(2): poses_o, st, _ = h.match_scan2scan_batch(sets, ident)
 t = h.get_timing(True)
-res["scan2scan"] = {"pairs": B, "ok": int((st == 0).sum()), "assoc_ms_per_launch": t.ms_odom / max(t.launches_odom, 1),
-                    "solve_ms_per_launch": t.ms_solve / max(t.launches_solve, 1),
-                    "pairs_per_s_gpu_only": B / (2 * (t.ms_odom / max(t.launches_odom, 1) + t.ms_solve / max(t.launches_solve, 1)) * 1e-3)}
+res["scan2scan"] = {"pairs": B, "ok": int((st == 0).sum()), "assoc_ms_per_call": t.ms_odom / 2, "solve_ms_per_call": t.ms_solve / 2,
+                    "targets_less_flat": int(sets[1][2][-1]), "queries": int(sets[2][2][-1] + sets[3][2][-1]),
+                    "plane_path": "brute" if os.environ.get("MSFL_ODOM_BRUTE") == "1" else "column-grid",
+                    "pairs_per_s_gpu_only": B / ((t.ms_odom + t.ms_solve) / 2 * 1e-3)}
 print(json.dumps(res))
