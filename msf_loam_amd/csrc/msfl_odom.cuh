@@ -313,14 +313,20 @@ assoc_scan2scan_wave_kernel(BatchView bv, OdomView ov, const double* __restrict_
 // cloud is not ring-monotone, has a ring >= 256, a point outside +-512 m or a non-finite
 // coordinate keep the brute-force kernel above (mode[b] = 1); results are identical either way.
 // ---------------------------------------------------------------------------------------------
-constexpr int kOdomCellBits = 10;                       // 1 m columns, +-512 m
+#ifndef MSFL_ODOM_SUB
+#define MSFL_ODOM_SUB 1
+#endif
+constexpr int kOdomSub = MSFL_ODOM_SUB;                  // columns per metre (1 or 2: scaling by it is exact in f32)
+constexpr int kOdomRange = 512;                         // +-512 m
+constexpr int kOdomCellBits = kOdomSub == 1 ? 10 : 11;
 constexpr int kOdomCellOff = 1 << (kOdomCellBits - 1);
 constexpr int kOdomPairBits = 32 - 2 * kOdomCellBits;   // pairs per sort chunk (4096)
 #ifndef MSFL_ODOM_LANES
 #define MSFL_ODOM_LANES 16
 #endif
 constexpr int kOdomLanes = MSFL_ODOM_LANES;             // lanes cooperating on one plane query
-constexpr int kOdomMaxLevel = 6;                        // gap >= 6 m  >  sqrt(25): nothing outside can pass the 25 m^2 gate
+constexpr int kOdomMidLevel = kOdomSub == 1 ? 2 : 3;
+constexpr int kOdomMaxLevel = 6 * kOdomSub;                        // gap >= 6 m  >  sqrt(25): nothing outside can pass the 25 m^2 gate
 
 __device__ __forceinline__ int odom_find_pair(const int* __restrict__ off, int B, int i) {
   int lo = 0, hi = B;                                   // largest b with off[b] <= i
@@ -341,10 +347,10 @@ odom_key_kernel(const float4* __restrict__ pts, const uint16_t* __restrict__ rin
   const float4 p = pts[i];
   const int j = i - off[b];
   const int r = ring[i];
-  bool bad = !(fabsf(p.x) < (float)kOdomCellOff && fabsf(p.y) < (float)kOdomCellOff && fabsf(p.z) < 1e30f) || r >= 256 || j >= (1 << 24);
+  bool bad = !(fabsf(p.x) < (float)kOdomRange && fabsf(p.y) < (float)kOdomRange && fabsf(p.z) < 1e30f) || r >= 256 || j >= (1 << 24);
   if (j > 0 && ring[i - 1] > r) bad = true;
   unsigned key = (unsigned)(b - b0) << (2 * kOdomCellBits);
-  if (!bad) key |= ((unsigned)((int)floorf(p.y) + kOdomCellOff) << kOdomCellBits) | (unsigned)((int)floorf(p.x) + kOdomCellOff);
+  if (!bad) key |= ((unsigned)((int)floorf(p.y * (float)kOdomSub) + kOdomCellOff) << kOdomCellBits) | (unsigned)((int)floorf(p.x * (float)kOdomSub) + kOdomCellOff);
   else mode[b] = 1;
   keys[i] = key;
   vals[i] = (unsigned)i;
@@ -413,7 +419,9 @@ __device__ __forceinline__ void odom_walk(const OdomIndex& ix, unsigned pair_bit
 // exact lower bound (squared, with a 1e-4 safety factor >> f32 rounding) on the distance from q to
 // any target outside the walked square of half-width r columns
 __device__ __forceinline__ float odom_gap_sq(float3 q, float fx, float fy, int r) {
-  const float g = fminf(fminf(q.x - (fx - (float)r), (fx + 1.f + (float)r) - q.x), fminf(q.y - (fy - (float)r), (fy + 1.f + (float)r) - q.y));
+  const float qx = q.x * (float)kOdomSub, qy = q.y * (float)kOdomSub;      // column units
+  const float g = fminf(fminf(qx - (fx - (float)r), (fx + 1.f + (float)r) - qx), fminf(qy - (fy - (float)r), (fy + 1.f + (float)r) - qy)) *
+                  (1.f / (float)kOdomSub);
   return g * g * 0.9999f;
 }
 
@@ -454,16 +462,16 @@ assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const
   if (ok) {
     const float4 f = bv.surf[bv.surf_off[b] + qf];
     q = transform_point_f32(load_pose(poses + 7 * b), f.x, f.y, f.z);
-    ok = fabsf(q.x) < (float)(kOdomCellOff + kOdomMaxLevel + 1) && fabsf(q.y) < (float)(kOdomCellOff + kOdomMaxLevel + 1);   // also rejects NaN
+    ok = fabsf(q.x) < (float)(kOdomRange + 7) && fabsf(q.y) < (float)(kOdomRange + 7);   // also rejects NaN
   }
   if (!ok) { if (sl < 4) out[sl] = 0.0; return; }
-  const float fx = floorf(q.x), fy = floorf(q.y);
+  const float fx = floorf(q.x * (float)kOdomSub), fy = floorf(q.y * (float)kOdomSub);
   const int cx = (int)fx + kOdomCellOff, cy = (int)fy + kOdomCellOff;
   const unsigned pair_bits = (unsigned)(b % ix.chunk) << (2 * kOdomCellBits);
   // ---- exact 1-NN (:169), ties -> lower index; w = ring << 24 | index, so (d, w & 0xffffff) orders candidates ----
   float best = INFINITY; int bw = 0x7fffffff;
   for (int l = 0; l < 3; l++) {
-    const int r = l == 0 ? 1 : l == 1 ? 2 : kOdomMaxLevel;
+    const int r = l == 0 ? 1 : l == 1 ? kOdomMidLevel : kOdomMaxLevel;
     odom_walk<L>(ix, pair_bits, s0, s1, cx, cy, r, sl, [&](const float4 p) {
       const float d = odom_dist(p, q);
       const int w = __float_as_int(p.w);
@@ -483,7 +491,7 @@ assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const
   float f2, f3, b2, b3;
   int jf2, jf3, jb2, jb3;
   for (int l = 0; l < 3; l++) {
-    const int r = l == 0 ? 1 : l == 1 ? 2 : kOdomMaxLevel;
+    const int r = l == 0 ? 1 : l == 1 ? kOdomMidLevel : kOdomMaxLevel;
     f2 = f3 = b2 = b3 = thr; jf2 = jf3 = 0x7fffffff; jb2 = jb3 = -1;      // each level re-walks the inner square too
     odom_walk<L>(ix, pair_bits, s0, s1, cx, cy, r, sl, [&](const float4 p) {
       const int w = __float_as_int(p.w), j = w & 0xffffff, rj = (int)((unsigned)w >> 24);
