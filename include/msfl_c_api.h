@@ -327,7 +327,7 @@ msfl_status msfl_extract_features_batch(msfl_handle* h, int n_scans,
 
 /* ------------------------------------------------------------------------------------------ */
 /* helpers on the caller side of the path: pcl::VoxelGrid down-sampling of  */
-/* the scan features before MatchScan2Map (laser_mapping.cc:264-270).                          */
+/* the scan features before MatchScan2Map (laser_mapping.cc:264-270) and TransformPointCloud.  */
 /* ------------------------------------------------------------------------------------------ */
 
 /* Centroid voxel filter with PCL VoxelGrid semantics (leaf cube, centroid of x,y,z,t per
@@ -336,6 +336,48 @@ msfl_status msfl_extract_features_batch(msfl_handle* h, int n_scans,
 msfl_status msfl_voxel_downsample(msfl_handle* h,
                                   const msfl_point* pts, int n, float leaf,
                                   msfl_point* out, int* n_out, msfl_mem mem);
+
+/* TransformPointCloud (laser_mapping.cc:24-31 -> TransformPoint, rigid_transform.h:131-137): every
+   point goes f32 -> f64 -> q*p + t -> f32, t (relative time) is carried over.  pose7 is always a
+   host array; in == out is allowed. */
+msfl_status msfl_transform_cloud(msfl_handle* h,
+                                 const msfl_point* in, int n, const double pose7[7],
+                                 msfl_point* out, msfl_mem mem);
+
+/* ------------------------------------------------------------------------------------------ */
+/* next row N3: per-point IMU deskew.                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* What GetDeltaQP reads of an IntegrationBase (integration_base.h:62-66): per IMU sample the
+   cumulative time and the pre-integrated rotation / position.  Always host arrays (a scan spans
+   ~40-50 samples); n >= 2, sum_dt non-decreasing. */
+typedef struct msfl_preintegration {
+  const double* sum_dt;   /* n */
+  const double* delta_q;  /* n x 4, [qx qy qz qw] */
+  const double* delta_p;  /* n x 3 */
+  int n;
+} msfl_preintegration;
+
+/* GetDeltaQP (scan_undistortion.cc:22-42) for every point's relative time pts[i].t: upper_bound
+   over sum_dt, Eigen slerp of delta_q (no normalisation), lerp of delta_p.  Writes the arrays
+   msfl_deskew takes (dq n x 4 [x y z w], dp n x 3).  Returns MSFL_BAD_ARG where the reference
+   CHECK-aborts (a time outside [sum_dt.front(), sum_dt.back()], :26-30).  A time equal to
+   sum_dt.back() makes the reference index one past the end (:37-39); here it yields the last
+   sample (s = 1). */
+msfl_status msfl_delta_qp(msfl_handle* h, const msfl_preintegration* pre,
+                          const msfl_point* pts, int n, double* dq, double* dp, msfl_mem mem);
+
+/* The deskew pass of LaserMapping (laser_mapping.cc:197-211), in place on one cloud:
+     p <- (dq(t) * p + R_odom^-1 * (velocity * t - 0.5 * gravity * t * t) + dp(t)).cast<float>()
+   rot_odom_xyzw = pose_odom_scan2world_.rotation() as [qx qy qz qw]. */
+msfl_status msfl_deskew_cloud(msfl_handle* h, const msfl_preintegration* pre,
+                              msfl_point* pts_io, int n, const double rot_odom_xyzw[4],
+                              const double velocity[3], const double gravity[3], msfl_mem mem);
+
+/* UndistortScanInternal (scan_undistortion.cc:5-19), in place: p <- dq(t).cast<float>() * p.
+   MSFL_BAD_ARG also for a negative time (CHECK_GE, :12). */
+msfl_status msfl_undistort_cloud(msfl_handle* h, const msfl_preintegration* pre,
+                                 msfl_point* pts_io, int n, msfl_mem mem);
 
 /* ------------------------------------------------------------------------------------------ */
 /* next row N1: the local map store kept resident on the device.               */

@@ -21,9 +21,15 @@ EXPORTED = [
     "msfl_set_map", "msfl_match_scan2map", "msfl_match_scan2map_batch", "msfl_match_scan2map_deskew",
     "msfl_associate_scan2map", "msfl_solve_records",
     "msfl_match_scan2scan", "msfl_match_scan2scan_batch", "msfl_extract_features",
-    "msfl_extract_features_batch", "msfl_voxel_downsample",
+    "msfl_extract_features_batch", "msfl_voxel_downsample", "msfl_transform_cloud",
+    "msfl_delta_qp", "msfl_deskew_cloud", "msfl_undistort_cloud",
     "msfl_grid_create", "msfl_grid_destroy", "msfl_grid_insert_scan", "msfl_grid_get_surrounded", "msfl_grid_size", "msfl_grid_dump",
 ]
+
+
+class Preintegration(C.Structure):
+    _fields_ = [("sum_dt", C.POINTER(C.c_double)), ("delta_q", C.POINTER(C.c_double)), ("delta_p", C.POINTER(C.c_double)),
+                ("n", C.c_int)]
 
 
 class Params(C.Structure):
@@ -354,6 +360,46 @@ class Handle:
         self._check(self.lib.msfl_voxel_downsample(self.h, _vp(pts), C.c_int(len(pts)), C.c_float(leaf), _vp(out),
                                                    C.byref(n_out), C.c_int(MEM_HOST)), "msfl_voxel_downsample")
         return out[:n_out.value].copy()
+
+    def transform_cloud(self, pts, pose7):
+        """TransformPointCloud (laser_mapping.cc:24-31)."""
+        pts = _pts(pts)
+        pose7 = np.ascontiguousarray(pose7, np.float64)
+        out = np.zeros_like(pts)
+        self._check(self.lib.msfl_transform_cloud(self.h, _vp(pts), C.c_int(len(pts)), _vp(pose7), _vp(out), C.c_int(MEM_HOST)),
+                    "msfl_transform_cloud")
+        return out
+
+    @staticmethod
+    def _preintegration(sum_dt, delta_q, delta_p):
+        keep = (np.ascontiguousarray(sum_dt, np.float64), np.ascontiguousarray(delta_q, np.float64).reshape(-1, 4),
+                np.ascontiguousarray(delta_p, np.float64).reshape(-1, 3))
+        pre = Preintegration(keep[0].ctypes.data_as(C.POINTER(C.c_double)), keep[1].ctypes.data_as(C.POINTER(C.c_double)),
+                             keep[2].ctypes.data_as(C.POINTER(C.c_double)), len(keep[0]))
+        return pre, keep
+
+    def delta_qp(self, sum_dt, delta_q, delta_p, pts):
+        """GetDeltaQP (scan_undistortion.cc:22-42) per point -> (status, dq (n,4), dp (n,3))."""
+        pts = _pts(pts)
+        pre, keep = self._preintegration(sum_dt, delta_q, delta_p)
+        dq, dp = np.zeros((len(pts), 4)), np.zeros((len(pts), 3))
+        s = self.lib.msfl_delta_qp(self.h, C.byref(pre), _vp(pts), C.c_int(len(pts)), _vp(dq), _vp(dp), C.c_int(MEM_HOST))
+        return s, dq, dp
+
+    def deskew_cloud(self, sum_dt, delta_q, delta_p, pts, rot_odom_xyzw, velocity, gravity):
+        """laser_mapping.cc:197-211 -> (status, deskewed points)."""
+        pts = _pts(pts).copy()
+        pre, keep = self._preintegration(sum_dt, delta_q, delta_p)
+        r, v, g = (np.ascontiguousarray(a, np.float64) for a in (rot_odom_xyzw, velocity, gravity))
+        s = self.lib.msfl_deskew_cloud(self.h, C.byref(pre), _vp(pts), C.c_int(len(pts)), _vp(r), _vp(v), _vp(g), C.c_int(MEM_HOST))
+        return s, pts
+
+    def undistort_cloud(self, sum_dt, delta_q, delta_p, pts):
+        """UndistortScanInternal (scan_undistortion.cc:5-19) -> (status, points)."""
+        pts = _pts(pts).copy()
+        pre, keep = self._preintegration(sum_dt, delta_q, delta_p)
+        s = self.lib.msfl_undistort_cloud(self.h, C.byref(pre), _vp(pts), C.c_int(len(pts)), C.c_int(MEM_HOST))
+        return s, pts
 
 
 class Grid:

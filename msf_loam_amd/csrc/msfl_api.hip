@@ -20,6 +20,7 @@
 #include "msfl_extract.cuh"
 #include "msfl_odom.cuh"
 #include "msfl_grid.cuh"
+#include "msfl_deskew.cuh"
 
 using namespace msfl;
 
@@ -112,6 +113,7 @@ struct msfl_handle_s {
   DevBuf dk[4];
   DevBuf ex[16];
   DevBuf od[16];
+  DevBuf pp[5];   // per-point passes: pre-integration samples, staged points, dq, dp, flag
 
   PinRing pin;
 
@@ -430,6 +432,7 @@ void msfl_destroy(msfl_handle* h) {
   for (auto& b : h->dk) b.release();
   for (auto& b : h->ex) b.release();
   for (auto& b : h->od) b.release();
+  for (auto& b : h->pp) b.release();
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -695,3 +698,4 @@ msfl_status msfl_solve_records(msfl_handle* h, const msfl_point* corner, int n_c
 
 #include "msfl_api_stage_ab.inc"
 #include "msfl_api_grid.inc"
+#include "msfl_api_deskew.inc"

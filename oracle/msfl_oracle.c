@@ -1334,3 +1334,87 @@ int orc_grid_dump(const orc_grid* g, orc_point* out, int capacity) {
     for (int i = 0; i < g->cells[c].n; i++) { if (m < capacity) out[m] = g->cells[c].pts[i]; m++; }
   return m;
 }
+
+/* ================================================================================================
+ * N3: IMU deskew inputs
+ * ============================================================================================== */
+
+/* Eigen 3.3 QuaternionBase::slerp (Geometry/Quaternion.h): coefficients blended with
+   sin((1-t)θ)/sinθ and sin(tθ)/sinθ, θ = acos|a·b|; linear when |a·b| >= 1 - eps; the second
+   weight flips sign for a negative dot; the result is NOT normalised. */
+static void eigen_slerp(const double a[4], const double b[4], double t, double out[4]) {
+  const double one = 1.0 - DBL_EPSILON;
+  const double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  const double ad = fabs(d);
+  double s0, s1;
+  if (ad >= one) { s0 = 1.0 - t; s1 = t; }
+  else {
+    const double theta = acos(ad), st = sin(theta);
+    s0 = sin((1.0 - t) * theta) / st;
+    s1 = sin(t * theta) / st;
+  }
+  if (d < 0.0) s1 = -s1;
+  for (int k = 0; k < 4; k++) out[k] = s0 * a[k] + s1 * b[k];
+}
+
+int orc_delta_qp(const double* sum_dt, const double* delta_q, const double* delta_p, int n_samples,
+                 double dt, double q_out[4], double p_out[3]) {
+  q_out[0] = q_out[1] = q_out[2] = 0.0; q_out[3] = 1.0;
+  p_out[0] = p_out[1] = p_out[2] = 0.0;
+  if (n_samples < 2 || !(dt <= sum_dt[n_samples - 1] && dt >= sum_dt[0])) return 1;      /* :26-30 */
+  int lo = 0, hi = n_samples;                                                            /* std::upper_bound, :33 */
+  while (lo < hi) { const int mid = (lo + hi) / 2; if (dt < sum_dt[mid]) hi = mid; else lo = mid + 1; }
+  int idx = lo - 1;                                                                      /* :35 */
+  if (idx > n_samples - 2) idx = n_samples - 2;
+  const double s = (dt - sum_dt[idx]) / (sum_dt[idx + 1] - sum_dt[idx]);                 /* :37 */
+  eigen_slerp(delta_q + 4 * idx, delta_q + 4 * idx + 4, s, q_out);                       /* :38 */
+  for (int k = 0; k < 3; k++) p_out[k] = (1 - s) * delta_p[3 * idx + k] + s * delta_p[3 * idx + 3 + k];   /* :39 */
+  return 0;
+}
+
+int orc_deskew_cloud(const double* sum_dt, const double* delta_q, const double* delta_p, int n_samples,
+                     orc_point* pts, int n, const double rot_odom[4], const double velocity[3],
+                     const double gravity[3]) {
+  const double conj[4] = {-rot_odom[0], -rot_odom[1], -rot_odom[2], rot_odom[3]};
+  int bad = 0;
+  for (int i = 0; i < n; i++) {
+    const double dt = (double)pts[i].t;                                                  /* auto dt = e.intensity, :200 */
+    double q[4], p[3];
+    if (orc_delta_qp(sum_dt, delta_q, delta_p, n_samples, dt, q, p)) { bad++; continue; }
+    const double e[3] = {(double)pts[i].x, (double)pts[i].y, (double)pts[i].z};
+    double a[3], m[3], b[3];
+    orc_quat_rotate(q, e, a);
+    for (int k = 0; k < 3; k++) m[k] = velocity[k] * dt - 0.5 * gravity[k] * dt * dt;
+    orc_quat_rotate(conj, m, b);
+    pts[i].x = (float)(a[0] + b[0] + p[0]);
+    pts[i].y = (float)(a[1] + b[1] + p[1]);
+    pts[i].z = (float)(a[2] + b[2] + p[2]);
+  }
+  return bad;
+}
+
+int orc_undistort_cloud(const double* sum_dt, const double* delta_q, const double* delta_p, int n_samples,
+                        orc_point* pts, int n) {
+  int bad = 0;
+  for (int i = 0; i < n; i++) {
+    double q[4], p[3];
+    if (!(pts[i].t >= 0.f) || orc_delta_qp(sum_dt, delta_q, delta_p, n_samples, (double)pts[i].t, q, p)) { bad++; continue; }
+    /* Quaternionf * Vector3f: Eigen _transformVector, uv = 2 (q.vec x v); v + w uv + q.vec x uv */
+    const float qx = (float)q[0], qy = (float)q[1], qz = (float)q[2], qw = (float)q[3];
+    const float x = pts[i].x, y = pts[i].y, z = pts[i].z;
+    float ux = qy * z - qz * y, uy = qz * x - qx * z, uz = qx * y - qy * x;
+    ux += ux; uy += uy; uz += uz;
+    const float cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
+    pts[i].x = x + qw * ux + cx; pts[i].y = y + qw * uy + cy; pts[i].z = z + qw * uz + cz;
+  }
+  return bad;
+}
+
+void orc_transform_cloud(const orc_point* in, int n, const double pose[7], orc_point* out) {
+  for (int i = 0; i < n; i++) {
+    const float v[3] = {in[i].x, in[i].y, in[i].z};
+    float o[3];
+    orc_transform_point(pose, v, o);
+    out[i].x = o[0]; out[i].y = o[1]; out[i].z = o[2]; out[i].t = in[i].t;
+  }
+}

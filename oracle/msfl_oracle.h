@@ -212,6 +212,23 @@ int orc_grid_get_surrounded(const orc_grid* g, const orc_point* scan, int n, con
 int orc_grid_size(const orc_grid* g, int* n_cells);
 /* all points, cells ascending, in-cell order as stored */
 int orc_grid_dump(const orc_grid* g, orc_point* out, int capacity);
+/* ---- N3: IMU deskew inputs ---------------------------------------------------------------- */
+/* GetDeltaQP (src/slam/imu_fusion/scan_undistortion.cc:22-42): upper_bound over sum_dt, Eigen
+   3.3 Quaternion::slerp (no normalisation, linear when |dot| >= 1 - eps), lerp of delta_p.
+   Returns 0, or 1 where the reference CHECK-aborts (dt outside [front, back]).  dt == back()
+   makes the reference read one past the end; restated as the last sample (s = 1). */
+int orc_delta_qp(const double* sum_dt, const double* delta_q, const double* delta_p, int n_samples,
+                 double dt, double q_out[4], double p_out[3]);
+/* laser_mapping.cc:197-211, in place; returns the number of points whose time is out of range */
+int orc_deskew_cloud(const double* sum_dt, const double* delta_q, const double* delta_p, int n_samples,
+                     orc_point* pts, int n, const double rot_odom[4], const double velocity[3],
+                     const double gravity[3]);
+/* UndistortScanInternal, scan_undistortion.cc:5-19 (rotation only, in f32) */
+int orc_undistort_cloud(const double* sum_dt, const double* delta_q, const double* delta_p, int n_samples,
+                        orc_point* pts, int n);
+/* TransformPointCloud, laser_mapping.cc:24-31 */
+void orc_transform_cloud(const orc_point* in, int n, const double pose[7], orc_point* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -295,6 +295,44 @@ def voxel_grid(pts, leaf):
     return out[:m].copy()
 
 
+# ---- N3: IMU deskew inputs ---------------------------------------------------------------------------
+
+def _pre(sum_dt, delta_q, delta_p):
+    return (np.ascontiguousarray(sum_dt, np.float64), np.ascontiguousarray(delta_q, np.float64).reshape(-1, 4),
+            np.ascontiguousarray(delta_p, np.float64).reshape(-1, 3))
+
+
+def delta_qp(sum_dt, delta_q, delta_p, dt):
+    """GetDeltaQP for one time -> (rc, q[4], p[3])."""
+    sd, dq, dp = _pre(sum_dt, delta_q, delta_p)
+    q, p = np.zeros(4), np.zeros(3)
+    rc = lib().orc_delta_qp(_p(sd), _p(dq), _p(dp), C.c_int(len(sd)), C.c_double(float(dt)), _p(q), _p(p))
+    return rc, q, p
+
+
+def deskew_cloud(sum_dt, delta_q, delta_p, pts, rot_odom, velocity, gravity):
+    sd, dq, dp = _pre(sum_dt, delta_q, delta_p)
+    pts = as_points(pts).copy()
+    r, v, g = (np.ascontiguousarray(a, np.float64) for a in (rot_odom, velocity, gravity))
+    bad = lib().orc_deskew_cloud(_p(sd), _p(dq), _p(dp), C.c_int(len(sd)), _p(pts), C.c_int(len(pts)), _p(r), _p(v), _p(g))
+    return bad, pts
+
+
+def undistort_cloud(sum_dt, delta_q, delta_p, pts):
+    sd, dq, dp = _pre(sum_dt, delta_q, delta_p)
+    pts = as_points(pts).copy()
+    bad = lib().orc_undistort_cloud(_p(sd), _p(dq), _p(dp), C.c_int(len(sd)), _p(pts), C.c_int(len(pts)))
+    return bad, pts
+
+
+def transform_cloud(pts, pose):
+    pts = as_points(pts)
+    out = np.zeros_like(pts)
+    pose = np.ascontiguousarray(pose, np.float64)
+    lib().orc_transform_cloud(_p(pts), C.c_int(len(pts)), _p(pose), _p(out))
+    return out
+
+
 # ---- N1: HybridGrid local map store ---------------------------------------------------------------
 
 class HybridGrid:
