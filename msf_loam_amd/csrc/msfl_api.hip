@@ -320,7 +320,7 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
     }
     {
       ScopedTimer timer(h, T_SOLVE);
-      hipLaunchKernelGGL(lm_solve_kernel<256>, dim3(B), dim3(256), 0, st, bv,
+      hipLaunchKernelGGL(lm_solve_kernel<kLmBlock>, dim3(B), dim3(kLmBlock), 0, st, bv,
                          deskew ? (const double*)dv.pprime : (const double*)nullptr,
                          (const double*)h->records.as<double>(), d_poses, d_status, d_info, it, sp);
     }
@@ -414,6 +414,15 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
 
 void msfl_destroy(msfl_handle* h) {
   if (!h) return;
+#ifdef MSFL_LM_PROFILE
+  {
+    unsigned long long v[8] = {0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(msfl::g_lm_prof), sizeof(v));
+    if (v[5]) fprintf(stderr, "[lm profile] per solve (100 MHz ticks): eval %.0f reduce %.0f serial %.0f total %.0f passes %.2f solves %llu\n",
+                      (double)v[0] / v[5], (double)v[1] / v[5], (double)v[2] / v[5], (double)v[3] / v[5], (double)v[4] / v[5], v[5]);
+  }
+#endif
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   collect_timing(h);
@@ -683,7 +692,7 @@ msfl_status msfl_solve_records(msfl_handle* h, const msfl_point* corner, int n_c
   }
   {
     ScopedTimer timer(h, T_SOLVE);
-    hipLaunchKernelGGL(lm_solve_kernel<256>, dim3(1), dim3(256), 0, h->stream, bv, (const double*)nullptr,
+    hipLaunchKernelGGL(lm_solve_kernel<kLmBlock>, dim3(1), dim3(kLmBlock), 0, h->stream, bv, (const double*)nullptr,
                        (const double*)h->records.as<double>(), h->poses.as<double>(), h->status.as<int>(), d_info, 0,
                        solver_params(h->prm, 0));
   }

@@ -508,7 +508,11 @@ __device__ __forceinline__ void huber_rho(double a, double s, double& rho0, doub
 // LDS-resident copy of the first K plane records + their points (44 B each, structure of arrays so
 // that consecutive lanes hit consecutive banks).  A solve re-reads every record in each of its ~4-7
 // evaluation passes: what fits here is fetched from HBM once per solve instead of once per pass.
-constexpr int kPlaneCache = 1728;     // 76 KB -> two 256-thread workgroups per CU
+#ifndef MSFL_LM_BLOCK
+#define MSFL_LM_BLOCK 256
+#endif
+constexpr int kLmBlock = MSFL_LM_BLOCK;                        // threads per scan in the LM solve
+constexpr int kPlaneCache = kLmBlock == 256 ? 1728 : 832;      // 76 KB x 2 workgroups per CU, or 36.6 KB x 4
 struct PlaneCache {
   double nx[kPlaneCache], ny[kPlaneCache], nz[kPlaneCache], d0[kPlaneCache];
   float px[kPlaneCache], py[kPlaneCache], pz[kPlaneCache];
@@ -554,10 +558,18 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   const bool use_cache = (pprime == nullptr);       // deskew keeps f64 points in global memory
   for (int i = threadIdx.x; i < ns; i += BLOCK) {
     d3 N, p; double d0;
+#ifdef MSFL_LM_FAKE_CACHE   /* timing experiment only: pretend every record is LDS-resident (wrong results) */
+    if (!FILL && use_cache) {
+      const int ii = i % kPlaneCache;
+      N = mk3(pc.nx[ii], pc.ny[ii], pc.nz[ii]); d0 = pc.d0[ii];
+      p = mk3((double)pc.px[ii], (double)pc.py[ii], (double)pc.pz[ii]);
+    } else {
+#else
     if (!FILL && use_cache && i < kPlaneCache) {
       N = mk3(pc.nx[i], pc.ny[i], pc.nz[i]); d0 = pc.d0[i];
       p = mk3((double)pc.px[i], (double)pc.py[i], (double)pc.pz[i]);
     } else {
+#endif
       const double* r4 = recp + 4 * (size_t)i;
       N = mk3(r4[0], r4[1], r4[2]); d0 = r4[3];
       if (pprime) { const size_t k = (size_t)(nc + i); p = mk3(pprime[3 * k], pprime[3 * k + 1], pprime[3 * k + 2]); }
@@ -823,6 +835,15 @@ __device__ __noinline__ int tr_decide(TrState& tr, const double* red, const Solv
   return 1;
 }
 
+#ifdef MSFL_LM_PROFILE
+__device__ unsigned long long g_lm_prof[8];   // cycles (lane 0, summed over workgroups): eval, reduce, serial, total, passes
+#define LM_T(x) const unsigned long long x = wall_clock64()
+#define LM_ADD(k, v) if (threadIdx.x == 0) atomicAdd(&g_lm_prof[k], (unsigned long long)(v))
+#else
+#define LM_T(x)
+#define LM_ADD(k, v)
+#endif
+
 // One workgroup per scan, persistent over all trust-region iterations of one ceres::Solve.
 // Lane 0 runs the (serial, tiny) trust-region logic between evaluation passes; every pass
 // evaluates cost AND the normal equations at the candidate, so an accepted step needs no second
@@ -845,14 +866,19 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
   const double* pprime = pprime_all ? pprime_all + 3 * r0 : nullptr;
   double* pose_g = poses + 7 * (size_t)b;
   TrState& tr = sh.tr;
-
+  LM_T(t_begin);
   {
     double acc[kAcc];
     int ne, np;
     const pose7 T = load_pose(pose_g);
+    LM_T(t0);
     evaluate_pass<BLOCK, true>(T, prm.huber, corner, nc, surf, ns, pprime, rec, s_cache, acc, ne, np);
+    LM_T(t1);
     block_reduce<BLOCK>(sh, acc, ne, np);
+    LM_T(t2);
+    LM_ADD(0, t1 - t0); LM_ADD(1, t2 - t1); LM_ADD(4, 1);
   }
+  LM_T(t_s0);
   if (threadIdx.x == 0) {
     const int n_edge = sh.cnt[0], n_plane = sh.cnt[1];
     int go = 1;
@@ -885,17 +911,26 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
     sh.go = go;
   }
   __syncthreads();
+  LM_T(t_s1);
+  LM_ADD(2, t_s1 - t_s0);
   bool solved = (sh.cnt[0] + sh.cnt[1] >= prm.min_correspondences) && (sh.cnt[0] + sh.cnt[1] > 0);
   while (sh.go) {
     double acc[kAcc];
     int ne, np;
     const pose7 T = load_pose(tr.cand);
     __syncthreads();                       // everyone has read go / cand before lane 0 may overwrite them
+    LM_T(t0);
     evaluate_pass<BLOCK, false>(T, prm.huber, corner, nc, surf, ns, pprime, rec, s_cache, acc, ne, np);
+    LM_T(t1);
     block_reduce<BLOCK>(sh, acc, ne, np);
+    LM_T(t2);
     if (threadIdx.x == 0) sh.go = tr_decide(tr, sh.red, prm) ? tr_propose(tr, prm) : 0;
     __syncthreads();
+    LM_T(t3);
+    LM_ADD(0, t1 - t0); LM_ADD(1, t2 - t1); LM_ADD(2, t3 - t2); LM_ADD(4, 1);
   }
+  LM_T(t_end);
+  LM_ADD(3, t_end - t_begin); LM_ADD(5, 1);
   if (threadIdx.x == 0) {
     if (solved) {
 #pragma unroll

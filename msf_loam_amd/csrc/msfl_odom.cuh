@@ -472,7 +472,7 @@ assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const
   float best = INFINITY; int bw = 0x7fffffff;
   for (int l = 0; l < 3; l++) {
     const int r = l == 0 ? 1 : l == 1 ? kOdomMidLevel : kOdomMaxLevel;
-    odom_walk<L>(ix, pair_bits, s0, s1, cx, cy, r, sl, [&](const float4 p) {
+    odom_walk<L>(ix, pair_bits, s0, s1, cx, cy, r, sl, [&](const float4 p) __attribute__((always_inline)) {
       const float d = odom_dist(p, q);
       const int w = __float_as_int(p.w);
       if (d < best || (d == best && (w & 0xffffff) < (bw & 0xffffff))) { best = d; bw = w; }
@@ -493,18 +493,21 @@ assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const
   for (int l = 0; l < 3; l++) {
     const int r = l == 0 ? 1 : l == 1 ? kOdomMidLevel : kOdomMaxLevel;
     f2 = f3 = b2 = b3 = thr; jf2 = jf3 = 0x7fffffff; jb2 = jb3 = -1;      // each level re-walks the inner square too
-    odom_walk<L>(ix, pair_bits, s0, s1, cx, cy, r, sl, [&](const float4 p) {
+    odom_walk<L>(ix, pair_bits, s0, s1, cx, cy, r, sl, [&](const float4 p) __attribute__((always_inline)) {
       const int w = __float_as_int(p.w), j = w & 0xffffff, rj = (int)((unsigned)w >> 24);
       if (j == closest || (float)rj > hi_ring || (float)rj < lo_ring) return;
       const float d = odom_dist(p, q);
       if (!(d < thr)) return;                                    // every running minimum starts at the 25 m^2 gate
-      if (j > closest) {
-        if (rj <= id) { if (d < f2 || (d == f2 && j < jf2)) { f2 = d; jf2 = j; } }
-        else { if (d < f3 || (d == f3 && j < jf3)) { f3 = d; jf3 = j; } }
-      } else {
-        if (rj >= id) { if (d < b2 || (d == b2 && j > jb2)) { b2 = d; jb2 = j; } }
-        else { if (d < b3 || (d == b3 && j > jb3)) { b3 = d; jb3 = j; } }
-      }
+      // branch-free updates (selects): branches here make the compiler address the minima through memory
+      const bool fwd = j > closest, same = fwd ? rj <= id : rj >= id;
+      const bool u_f2 = fwd && same && (d < f2 || (d == f2 && j < jf2));
+      const bool u_f3 = fwd && !same && (d < f3 || (d == f3 && j < jf3));
+      const bool u_b2 = !fwd && same && (d < b2 || (d == b2 && j > jb2));
+      const bool u_b3 = !fwd && !same && (d < b3 || (d == b3 && j > jb3));
+      f2 = u_f2 ? d : f2; jf2 = u_f2 ? j : jf2;
+      f3 = u_f3 ? d : f3; jf3 = u_f3 ? j : jf3;
+      b2 = u_b2 ? d : b2; jb2 = u_b2 ? j : jb2;
+      b3 = u_b3 ? d : b3; jb3 = u_b3 ? j : jb3;
     });
     group_min_lo<L>(f2, jf2); group_min_lo<L>(f3, jf3); group_min_hi<L>(b2, jb2); group_min_hi<L>(b3, jb3);
     const float g = odom_gap_sq(q, fx, fy, r);

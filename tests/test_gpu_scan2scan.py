@@ -163,3 +163,32 @@ def test_column_grid_planes_equal_brute_force(gpu, oracle, monkeypatch):
     finally:
         h2.close()
     assert np.array_equal(status, status2) and np.array_equal(poses, poses2)
+
+
+def test_empty_and_nonfinite_clouds(gpu, oracle):
+    """Empty previous-scan clouds (the reference never guards them, odometry_scan_matcher.cc:57-61) give
+    'too few correspondences'; NaN points must not poison neighbours, on any of the three kernels."""
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    base = list(_clouds(*_pair(oracle, 1)))
+    e4, e1 = np.zeros((0, 4), np.float32), np.zeros(0, np.uint16)
+    s, p, _ = gpu.match_scan2scan(e4, e1, e4, e1, base[4], base[5], ident)
+    assert s == capi.TOO_FEW_CORRESPONDENCES and np.array_equal(p, ident)
+    rc, po, _ = oracle.match_scan2scan(e4, e1, e4, e1, base[4], base[5], ident)
+    assert rc == 1 and np.array_equal(po, ident)
+    s, p, _ = gpu.match_scan2scan(base[0], base[1], base[2], base[3], e4, e4, ident)      # nothing to match
+    assert s == capi.TOO_FEW_CORRESPONDENCES and np.array_equal(p, ident)
+    # NaN in a target and in a query: those points never match, everything else is unaffected by the path taken
+    nan_t = [np.copy(a) for a in base]
+    nan_t[2][100, 1] = np.nan
+    nan_q = [np.copy(a) for a in base]
+    nan_q[5][7, 0] = np.nan
+    variants = [base, nan_t, nan_q]
+    pairs = [variants[i % 3] for i in range(45)]
+    guesses = np.stack([ident] * 45)
+    guesses[:, 0] = np.linspace(-0.2, 0.2, 45)
+    poses, status, info = gpu.match_scan2scan_batch(_batch_sets(pairs), guesses, want_info=True)
+    for b in range(45):
+        s, p, i1 = gpu.match_scan2scan(*pairs[b], guesses[b])
+        assert s == status[b] == 0 and np.array_equal(p, poses[b]), b
+        assert np.all(np.isfinite(p))
+    assert info[2].n_plane[0] in (info[0].n_plane[0], info[0].n_plane[0] - 1)         # the NaN query drops out, nothing else
