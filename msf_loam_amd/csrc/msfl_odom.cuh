@@ -300,96 +300,130 @@ assoc_scan2scan_wave_kernel(BatchView bv, OdomView ov, const double* __restrict_
 
 // ---------------------------------------------------------------------------------------------
 // Throughput path for the plane queries (384 flat features x ~20 k less-flat targets per pair is
-// >95 % of the brute-force work).  The previous scans' less-flat clouds are bucketed into a
-// 1 m x-y column grid — one radix sort over the whole batch with key (pair | cy | cx), so every
-// pair keeps its own contiguous segment and a row of x-adjacent columns is one contiguous run —
-// and each query walks the 3x3, 5x5 and 13x13 column neighbourhoods until the exact lower bound
-// of everything outside the walked square exceeds what it has found.
+// >95 % of the brute-force work).  Each previous scan's less-flat cloud is bucketed into 1 m x-y
+// columns by ONE workgroup with an LDS counting sort (u16 counters, <= 40 960 columns = 80 KB):
+// bounding box -> histogram -> exclusive scan -> scatter, three streaming passes over ~20 k
+// points.  The column starts go to a dense per-pair table, so a row of x-adjacent columns is one
+// contiguous run bounded by two table entries.  A query walks the 3x3, 5x5 and 13x13 column
+// neighbourhoods until the exact lower bound of everything outside the walked square exceeds
+// what it has found.
 //
 // The ring-window scans (:183-232) are index-ordered sweeps with `break`; on a cloud whose rings
 // are non-decreasing in array order (what scan registration produces, msf_loam_node.cc:243-356)
 // they select exactly {j > closest, ring <= id + 2.5} and {j < closest, ring >= id - 2.5}, and the
 // running strict '<' minima become lexicographic minima over (distance, index).  Pairs whose
-// cloud is not ring-monotone, has a ring >= 256, a point outside +-512 m or a non-finite
-// coordinate keep the brute-force kernel above (mode[b] = 1); results are identical either way.
+// cloud is not ring-monotone, has a ring >= 256, more than 65 535 points, a non-finite or
+// > 512 m coordinate, or a footprint of more than 40 960 columns keep the brute-force kernel
+// above (mode[b] = 1); results are identical either way.
 // ---------------------------------------------------------------------------------------------
-#ifndef MSFL_ODOM_SUB
-#define MSFL_ODOM_SUB 1
-#endif
-constexpr int kOdomSub = MSFL_ODOM_SUB;                  // columns per metre (1 or 2: scaling by it is exact in f32)
-constexpr int kOdomRange = 512;                         // +-512 m
-constexpr int kOdomCellBits = kOdomSub == 1 ? 10 : 11;
-constexpr int kOdomCellOff = 1 << (kOdomCellBits - 1);
-constexpr int kOdomPairBits = 32 - 2 * kOdomCellBits;   // pairs per sort chunk (4096)
+constexpr int kOdomRange = 512;                         // columns are addressed relative to the cloud's bounding box
+constexpr int kOdomMaxCells = 40960;                    // u16 counters: 80 KB of LDS
+constexpr int kOdomTabStride = kOdomMaxCells + 1;       // per-pair table of column starts (+ end sentinel)
 #ifndef MSFL_ODOM_LANES
 #define MSFL_ODOM_LANES 16
 #endif
 constexpr int kOdomLanes = MSFL_ODOM_LANES;             // lanes cooperating on one plane query
-constexpr int kOdomMidLevel = kOdomSub == 1 ? 2 : 3;
-constexpr int kOdomMaxLevel = 6 * kOdomSub;                        // gap >= 6 m  >  sqrt(25): nothing outside can pass the 25 m^2 gate
+constexpr int kOdomMidLevel = 2;
+constexpr int kOdomMaxLevel = 6;                        // gap >= 6 m  >  sqrt(25): nothing outside can pass the 25 m^2 gate
 
-__device__ __forceinline__ int odom_find_pair(const int* __restrict__ off, int B, int i) {
-  int lo = 0, hi = B;                                   // largest b with off[b] <= i
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
-  return lo;
-}
-
-// key per less-flat target; pairs [b0, b0 + nb) form one sort chunk
-__global__ void __launch_bounds__(256)
-odom_key_kernel(const float4* __restrict__ pts, const uint16_t* __restrict__ ring, const int* __restrict__ off, int B, int b0, int nb,
-                unsigned* __restrict__ keys, unsigned* __restrict__ vals, int* __restrict__ mode) {
-  const int base = off[b0];
-  const int n = off[b0 + nb] - base;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const int i = base + t;
-  const int b = b0 + odom_find_pair(off + b0, nb, i);
-  const float4 p = pts[i];
-  const int j = i - off[b];
-  const int r = ring[i];
-  bool bad = !(fabsf(p.x) < (float)kOdomRange && fabsf(p.y) < (float)kOdomRange && fabsf(p.z) < 1e30f) || r >= 256 || j >= (1 << 24);
-  if (j > 0 && ring[i - 1] > r) bad = true;
-  unsigned key = (unsigned)(b - b0) << (2 * kOdomCellBits);
-  if (!bad) key |= ((unsigned)((int)floorf(p.y * (float)kOdomSub) + kOdomCellOff) << kOdomCellBits) | (unsigned)((int)floorf(p.x * (float)kOdomSub) + kOdomCellOff);
-  else mode[b] = 1;
-  keys[i] = key;
-  vals[i] = (unsigned)i;
-}
-
-// sorted target record: xyz + (ring << 24 | index within the pair's cloud)
-__global__ void __launch_bounds__(256)
-odom_gather_kernel(const float4* __restrict__ pts, const uint16_t* __restrict__ ring, const int* __restrict__ off, int b0,
-                   const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, int first, int n, float4* __restrict__ sorted) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const int i = first + t;
-  const int src = (int)vals[i];
-  const int b = b0 + (int)(keys[i] >> (2 * kOdomCellBits));
-  float4 p = pts[src];
-  p.w = __int_as_float((int)(((unsigned)ring[src] & 0xffu) << 24 | (unsigned)(src - off[b])));
-  sorted[i] = p;
-}
+struct OdomPairDesc { int ox, oy, W, H; };              // column (cx, cy) = (floor(x) - ox, floor(y) - oy), 0 <= cx < W
 
 struct OdomIndex {
-  const unsigned* keys;      // sorted, aligned with `sorted`
-  const float4* sorted;
+  const unsigned* tab;       // B x kOdomTabStride column starts, relative to the pair's segment
+  const float4* sorted;      // targets in column order: xyz + (ring << 24 | index within the pair's cloud)
+  const OdomPairDesc* desc;
   const int* mode;           // per pair: 0 = column grid, 1 = brute force
-  int chunk;                 // pairs per sort chunk; a key's pair field is b % chunk
 };
 
-__device__ __forceinline__ int odom_lower_bound(const unsigned* __restrict__ keys, int lo, int hi, unsigned key) {
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
-  return lo;
+__global__ void __launch_bounds__(1024)
+odom_bin_kernel(const float4* __restrict__ pts_all, const uint16_t* __restrict__ ring_all, const int* __restrict__ off,
+                unsigned* __restrict__ tab_all, float4* __restrict__ sorted_all, OdomPairDesc* __restrict__ desc, int* __restrict__ mode) {
+  __shared__ unsigned s_cnt[kOdomMaxCells / 2];         // two u16 counters per word
+  __shared__ int s_red[16][5];
+  __shared__ unsigned s_part[16];
+  __shared__ int s_box[5];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s0 = off[b], n = off[b + 1] - s0;
+  const float4* pts = pts_all + s0;
+  const uint16_t* ring = ring_all + s0;
+  unsigned* tab = tab_all + (size_t)b * kOdomTabStride;
+  // ---- bounding box in columns + the conditions the grid relies on ----
+  int lox = INT32_MAX, loy = INT32_MAX, hix = INT32_MIN, hiy = INT32_MIN, bad = n > 65535 ? 1 : 0;
+  for (int i = tid; i < n; i += 1024) {
+    const float4 p = pts[i];
+    const int r = ring[i];
+    if (!(fabsf(p.x) < (float)kOdomRange && fabsf(p.y) < (float)kOdomRange && fabsf(p.z) < 1e30f) || r >= 256) { bad = 1; continue; }
+    if (i > 0 && ring[i - 1] > r) bad = 1;
+    const int cx = (int)floorf(p.x), cy = (int)floorf(p.y);
+    lox = min(lox, cx); hix = max(hix, cx); loy = min(loy, cy); hiy = max(hiy, cy);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lox = min(lox, __shfl_xor(lox, o)); loy = min(loy, __shfl_xor(loy, o));
+    hix = max(hix, __shfl_xor(hix, o)); hiy = max(hiy, __shfl_xor(hiy, o)); bad |= __shfl_xor(bad, o);
+  }
+  if (lane == 0) { s_red[wave][0] = lox; s_red[wave][1] = loy; s_red[wave][2] = hix; s_red[wave][3] = hiy; s_red[wave][4] = bad; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; w++) {
+      lox = min(lox, s_red[w][0]); loy = min(loy, s_red[w][1]); hix = max(hix, s_red[w][2]); hiy = max(hiy, s_red[w][3]); bad |= s_red[w][4];
+    }
+    int W = 0, H = 0;
+    if (n > 0 && !bad) { W = hix - lox + 1; H = hiy - loy + 1; if ((long long)W * H > kOdomMaxCells) bad = 1; }
+    s_box[0] = lox; s_box[1] = loy; s_box[2] = W; s_box[3] = H; s_box[4] = bad;
+    OdomPairDesc d; d.ox = lox; d.oy = loy; d.W = bad ? 0 : W; d.H = bad ? 0 : H;
+    desc[b] = d;
+    mode[b] = bad ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_box[4] || n == 0) return;
+  const int ox = s_box[0], oy = s_box[1], W = s_box[2], cells = W * s_box[3];
+  // ---- histogram ----
+  for (int k = tid; k < (cells + 1) / 2; k += 1024) s_cnt[k] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    const float4 p = pts[i];
+    const int c = ((int)floorf(p.y) - oy) * W + ((int)floorf(p.x) - ox);
+    atomicAdd(&s_cnt[c >> 1], 1u << (16 * (c & 1)));
+  }
+  __syncthreads();
+  // ---- exclusive scan: every thread owns an even-sized run of columns ----
+  const int per = (((cells + 1023) / 1024) + 1) & ~1;
+  const int c0 = min(tid * per, cells), c1 = min(c0 + per, cells);
+  unsigned sum = 0;
+  for (int c = c0; c < c1; c++) sum += (s_cnt[c >> 1] >> (16 * (c & 1))) & 0xffffu;
+  unsigned incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  if (lane == 63) s_part[wave] = incl;
+  __syncthreads();
+  unsigned run = incl - sum;
+  for (int w = 0; w < wave; w++) run += s_part[w];
+  for (int c = c0; c < c1; c++) { tab[c] = run; run += (s_cnt[c >> 1] >> (16 * (c & 1))) & 0xffffu; }
+  if (tid == 0) tab[cells] = (unsigned)n;
+  __threadfence_block();
+  __syncthreads();
+  // ---- scatter: a column's points land in its run in arbitrary order (the minima are order-free) ----
+  float4* sorted = sorted_all + s0;
+  for (int i = tid; i < n; i += 1024) {
+    float4 p = pts[i];
+    const int c = ((int)floorf(p.y) - oy) * W + ((int)floorf(p.x) - ox);
+    const unsigned sh = 16 * (c & 1);
+    const unsigned old = atomicSub(&s_cnt[c >> 1], 1u << sh);
+    const unsigned k = ((old >> sh) & 0xffffu) - 1u;
+    p.w = __int_as_float((int)(((unsigned)ring[i] & 0xffu) << 24 | (unsigned)i));
+    sorted[tab[c] + k] = p;
+  }
 }
 
 // L lanes (a power of two, one query per L-lane group) walk the (2r+1)^2 column square around
-// (cx, cy) of the pair segment [s0, s1): the 2 x rows run boundaries are binary-searched one per
-// lane, then every row's run is read L targets at a time (coalesced); f(float4) per target.
+// column (cx, cy): the 2 x rows run boundaries are fetched from the table one per lane, then every
+// row's run is read L targets at a time (coalesced); f(float4) per target.
 template <int L, class F>
-__device__ __forceinline__ void odom_walk(const OdomIndex& ix, unsigned pair_bits, int s0, int s1, int cx, int cy, int r, int sl, F&& f) {
-  const int lim = (1 << kOdomCellBits) - 1;
-  const int x0 = max(cx - r, 0), x1 = min(cx + r, lim);
-  const int y0 = max(cy - r, 0), y1 = min(cy + r, lim);
+__device__ __forceinline__ void odom_walk(const OdomIndex& ix, const unsigned* __restrict__ tab, const float4* __restrict__ sorted,
+                                          int W, int H, int cx, int cy, int r, int sl, F&& f) {
+  const int x0 = max(cx - r, 0), x1 = min(cx + r, W - 1);
+  const int y0 = max(cy - r, 0), y1 = min(cy + r, H - 1);
   if (x0 > x1 || y0 > y1) return;
   const int n_search = 2 * (y1 - y0 + 1);                  // <= 26
   constexpr int kRounds = (2 * (2 * kOdomMaxLevel + 1) + L - 1) / L;
@@ -397,12 +431,8 @@ __device__ __forceinline__ void odom_walk(const OdomIndex& ix, unsigned pair_bit
 #pragma unroll
   for (int k = 0; k < kRounds; k++) {
     const int sidx = k * L + sl;
-    res[k] = s1;
-    if (sidx < n_search) {
-      const unsigned row = pair_bits | ((unsigned)(y0 + (sidx >> 1)) << kOdomCellBits);
-      // run of the row = [lower_bound(row | x0), lower_bound(row | x1 + 1)); x1 + 1 may carry into the y field: still the right bound
-      res[k] = odom_lower_bound(ix.keys, s0, s1, (sidx & 1) ? row + (unsigned)x1 + 1u : row | (unsigned)x0);
-    }
+    res[k] = 0;
+    if (sidx < n_search) res[k] = (int)tab[(y0 + (sidx >> 1)) * W + ((sidx & 1) ? x1 + 1 : x0)];   // row-major: the run ends where column x1 + 1 starts
   }
   for (int row = 0; row <= y1 - y0; row++) {
     int b0 = 0, b1 = 0;
@@ -412,16 +442,14 @@ __device__ __forceinline__ void odom_walk(const OdomIndex& ix, unsigned pair_bit
       if ((2 * row) / L == k) b0 = v0;
       if ((2 * row + 1) / L == k) b1 = v1;
     }
-    for (int i = b0 + sl; i < b1; i += L) f(ix.sorted[i]);
+    for (int i = b0 + sl; i < b1; i += L) f(sorted[i]);
   }
 }
 
 // exact lower bound (squared, with a 1e-4 safety factor >> f32 rounding) on the distance from q to
 // any target outside the walked square of half-width r columns
 __device__ __forceinline__ float odom_gap_sq(float3 q, float fx, float fy, int r) {
-  const float qx = q.x * (float)kOdomSub, qy = q.y * (float)kOdomSub;      // column units
-  const float g = fminf(fminf(qx - (fx - (float)r), (fx + 1.f + (float)r) - qx), fminf(qy - (fy - (float)r), (fy + 1.f + (float)r) - qy)) *
-                  (1.f / (float)kOdomSub);
+  const float g = fminf(fminf(q.x - (fx - (float)r), (fx + 1.f + (float)r) - q.x), fminf(q.y - (fy - (float)r), (fy + 1.f + (float)r) - q.y));
   return g * g * 0.9999f;
 }
 
@@ -465,14 +493,16 @@ assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const
     ok = fabsf(q.x) < (float)(kOdomRange + 7) && fabsf(q.y) < (float)(kOdomRange + 7);   // also rejects NaN
   }
   if (!ok) { if (sl < 4) out[sl] = 0.0; return; }
-  const float fx = floorf(q.x * (float)kOdomSub), fy = floorf(q.y * (float)kOdomSub);
-  const int cx = (int)fx + kOdomCellOff, cy = (int)fy + kOdomCellOff;
-  const unsigned pair_bits = (unsigned)(b % ix.chunk) << (2 * kOdomCellBits);
+  const float fx = floorf(q.x), fy = floorf(q.y);
+  const OdomPairDesc pd = ix.desc[b];
+  const int cx = (int)fx - pd.ox, cy = (int)fy - pd.oy;           // may lie outside [0, W) x [0, H): the walk clips
+  const unsigned* tab = ix.tab + (size_t)b * kOdomTabStride;
+  const float4* sorted = ix.sorted + s0;
   // ---- exact 1-NN (:169), ties -> lower index; w = ring << 24 | index, so (d, w & 0xffffff) orders candidates ----
   float best = INFINITY; int bw = 0x7fffffff;
   for (int l = 0; l < 3; l++) {
     const int r = l == 0 ? 1 : l == 1 ? kOdomMidLevel : kOdomMaxLevel;
-    odom_walk<L>(ix, pair_bits, s0, s1, cx, cy, r, sl, [&](const float4 p) __attribute__((always_inline)) {
+    odom_walk<L>(ix, tab, sorted, pd.W, pd.H, cx, cy, r, sl, [&](const float4 p) __attribute__((always_inline)) {
       const float d = odom_dist(p, q);
       const int w = __float_as_int(p.w);
       if (d < best || (d == best && (w & 0xffffff) < (bw & 0xffffff))) { best = d; bw = w; }
@@ -493,7 +523,7 @@ assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const
   for (int l = 0; l < 3; l++) {
     const int r = l == 0 ? 1 : l == 1 ? kOdomMidLevel : kOdomMaxLevel;
     f2 = f3 = b2 = b3 = thr; jf2 = jf3 = 0x7fffffff; jb2 = jb3 = -1;      // each level re-walks the inner square too
-    odom_walk<L>(ix, pair_bits, s0, s1, cx, cy, r, sl, [&](const float4 p) __attribute__((always_inline)) {
+    odom_walk<L>(ix, tab, sorted, pd.W, pd.H, cx, cy, r, sl, [&](const float4 p) __attribute__((always_inline)) {
       const int w = __float_as_int(p.w), j = w & 0xffffff, rj = (int)((unsigned)w >> 24);
       if (j == closest || (float)rj > hi_ring || (float)rj < lo_ring) return;
       const float d = odom_dist(p, q);
