@@ -55,102 +55,129 @@ __device__ __forceinline__ bool point_valid(float4 p, double min_range) {
   return !((double)nrm < min_range || !isfinite(p.x) || !isfinite(p.y) || !isfinite(p.z));
 }
 
+// Each of the 16 wavefronts owns a CONTIGUOUS slice of the driver-order cloud, so the stable ring
+// split needs no per-chunk workgroup barriers: pass A counts (wave, ring) populations, one scan
+// turns them into write cursors, pass B re-walks the slice and scatters with wave-local ranks
+// (ballot per distinct ring; the cursors of a wave are touched by that wave only).
 __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, ExtractParams prm) {
-  __shared__ int s_cnt[kMaxRings];
   __shared__ int s_off[kMaxRings + 1];
-  __shared__ int s_base[kMaxRings];
   __shared__ int s_wrap[kMaxRings];
-  __shared__ int s_wavecnt[16][kMaxRings];
-  __shared__ int s_first, s_bad;
+  __shared__ int s_cur[16][kMaxRings];      // pass A: population of (wave, ring); pass B: write cursor
+  __shared__ int s_first[16], s_badw[16];
+  __shared__ int s_flag[2];
   __shared__ double s_start_ori;
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int o = v.off[b];
   const int n = v.off[b + 1] - o;
   const float4* in = v.in_pts + o;
   const uint16_t* in_ring = v.in_ring + o;
-  if (tid < kMaxRings) s_cnt[tid] = 0;
-  if (tid == 0) { s_first = 0x7fffffff; s_bad = 0; }
+  for (int k = tid; k < 16 * kMaxRings; k += 1024) (&s_cur[0][0])[k] = 0;
   __syncthreads();
-  // P1: count valid points per ring, find the first valid point
-  for (int i = tid; i < n; i += 1024) {
-    const float4 p = in[i];
-    if (point_valid(p, prm.min_range)) {
-      const int r = in_ring[i];
-      if (r >= kMaxRings) s_bad = 1;                      // CHECK_LT(point.ring, 128), :136
-      else atomicAdd(&s_cnt[r], 1);
-      atomicMin(&s_first, i);
+  const int slice = ((n + 15) / 16 + 63) & ~63;            // multiple of 64: a 64-point group never straddles two waves
+  const int w0 = min(wave * slice, n), w1 = min(w0 + slice, n);
+  // ---- pass A: populations, first valid point, ring check ----
+  int first = 0x7fffffff, bad = 0;
+  for (int g = w0; g < w1; g += 64) {
+    const int i = g + lane;
+    bool valid = false;
+    int r = -1;
+    if (i < w1) {
+      valid = point_valid(in[i], prm.min_range);
+      if (valid) { r = in_ring[i]; if (r >= kMaxRings) { bad = 1; valid = false; } }   // CHECK_LT(point.ring, 128), :136
+    }
+    unsigned long long remaining = __ballot(valid);
+    if (remaining && first == 0x7fffffff) first = g + (__ffsll((long long)remaining) - 1);
+    while (remaining) {
+      const int leader = __ffsll((long long)remaining) - 1;
+      const int lead_ring = __shfl(r, leader);
+      const unsigned long long m = __ballot(valid && r == lead_ring);
+      if (lane == leader) s_cur[wave][lead_ring] += __popcll(m);
+      remaining &= ~m;
     }
   }
+  bad = __any(bad) ? 1 : 0;
+  if (lane == 0) { s_first[wave] = first; s_badw[wave] = bad; }
   __syncthreads();
-  if (s_bad || s_first == 0x7fffffff) {
+  if (tid == 0) {
+    int f = 0x7fffffff, bd = 0;
+    for (int w = 0; w < 16; w++) { f = min(f, s_first[w]); bd |= s_badw[w]; }
+    s_flag[0] = f; s_flag[1] = bd;
+  }
+  // ring totals -> s_off (exclusive), then (wave, ring) cursors
+  if (tid < kMaxRings) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) t += s_cur[w][tid];
+    s_wrap[tid] = t;                                          // borrowed as the ring total
+  }
+  __syncthreads();
+  if (s_flag[1] || s_flag[0] == 0x7fffffff) {
     if (tid == 0) {
-      v.status[b] = s_bad ? 5 /*MSFL_BAD_RING*/ : 3 /*MSFL_BAD_ARG: empty valid cloud, CHECK :186,:200*/;
+      v.status[b] = s_flag[1] ? 5 /*MSFL_BAD_RING*/ : 3 /*MSFL_BAD_ARG: empty valid cloud, CHECK :186,:200*/;
       v.n_full[b] = 0; v.n_sharp[b] = 0; v.n_less_sharp[b] = 0; v.n_flat[b] = 0; v.n_less_flat[b] = 0;
     }
     if (tid <= kMaxRings) v.ring_tab[b * (kMaxRings + 1) + tid] = 0;
     return;
   }
-  // P2: ring offsets
   if (tid == 0) {
     int run = 0;
-    for (int r = 0; r < kMaxRings; r++) { s_off[r] = run; run += s_cnt[r]; }
+    for (int r = 0; r < kMaxRings; r++) { s_off[r] = run; run += s_wrap[r]; }
     s_off[kMaxRings] = run;
-    const float4 f = in[s_first];
+    const float4 f = in[s_flag[0]];
     s_start_ori = -atan2((double)f.y, (double)f.x);       // :131
   }
   __syncthreads();
   if (tid <= kMaxRings) v.ring_tab[b * (kMaxRings + 1) + tid] = s_off[tid];
-  if (tid < kMaxRings) s_base[tid] = s_off[tid];
+  if (tid < kMaxRings) {
+    int run = s_off[tid];
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const int t = s_cur[w][tid]; s_cur[w][tid] = run; run += t; }
+    s_wrap[tid] = 0x7fffffff;
+  }
+  __syncthreads();
   const int N = s_off[kMaxRings];
   const double start_ori = s_start_ori;
   const double two_pi = 2 * 3.14159265358979323846;
   float4* out_pts = v.full_pts + o;
   uint16_t* out_ring = v.full_ring + o;
   double* rel = v.rel + o;
-  // P3: stable split into rings, chunk by chunk in driver order
-  for (int base = 0; base < n; base += 1024) {
-    for (int k = tid; k < 16 * kMaxRings; k += 1024) (&s_wavecnt[0][0])[k] = 0;
-    __syncthreads();
-    const int i = base + tid;
+  // ---- pass B: stable split into rings, every wave in its own slice, driver order ----
+  for (int g = w0; g < w1; g += 64) {
+    const int i = g + lane;
     float4 p = make_float4(0, 0, 0, 0);
     int r = -1;
     bool valid = false;
-    if (i < n) {
+    if (i < w1) {
       p = in[i];
       valid = point_valid(p, prm.min_range);
       if (valid) r = in_ring[i];
     }
-    int rank = 0;
+    int dst = 0;
     unsigned long long remaining = __ballot(valid);
     while (remaining) {
       const int leader = __ffsll((long long)remaining) - 1;
       const int lead_ring = __shfl(r, leader);
       const unsigned long long m = __ballot(valid && r == lead_ring);
-      if (valid && r == lead_ring) rank = __popcll(m & ((1ull << lane) - 1ull));
-      if (lane == leader) s_wavecnt[wave][lead_ring] = __popcll(m);
+      const int cur = s_cur[wave][lead_ring];                // uniform read, before the leader advances it
+      if (valid && r == lead_ring) dst = cur + __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == leader) s_cur[wave][lead_ring] = cur + __popcll(m);
       remaining &= ~m;
     }
-    __syncthreads();
-    if (tid < kMaxRings) {
-      int run = s_base[tid];
-#pragma unroll
-      for (int w = 0; w < 16; w++) { const int t = s_wavecnt[w][tid]; s_wavecnt[w][tid] = run; run += t; }
-      s_base[tid] = run;
-    }
-    __syncthreads();
     if (valid) {
-      const int dst = s_wavecnt[wave][r] + rank;
       const double ori = -atan2((double)p.y, (double)p.x);                 // :139
-      rel[dst] = fmod(ori - start_ori + two_pi, two_pi);                   // :142
+      // fmod(a, 2 pi) with a = ori - start_ori + 2 pi in [0, 4 pi]: fmod is exact and so is a - 2 pi for
+      // 2 pi <= a <= 4 pi (Sterbenz), so two conditional subtractions give the same bits (:142)
+      double a = ori - start_ori + two_pi;
+      if (a >= two_pi) a -= two_pi;
+      if (a >= two_pi) a -= two_pi;
+      rel[dst] = a;
       out_pts[dst] = make_float4(p.x, p.y, p.z, 0.f);
       out_ring[dst] = (uint16_t)r;
     }
-    __syncthreads();
   }
+  __syncthreads();
   // P4: per ring, the first point whose raw angle is below its predecessor's: from there on the
   // reference adds 2 pi (a prefix-OR of `relative_angle < last_relative_angles[ring]`, :145-149)
-  if (tid < kMaxRings) s_wrap[tid] = 0x7fffffff;
-  __syncthreads();
   for (int i = tid; i < N; i += 1024) {
     const int r = out_ring[i];
     if (i > s_off[r] && rel[i] < rel[i - 1]) atomicMin(&s_wrap[r], i);
