@@ -337,6 +337,20 @@ msfl_status msfl_voxel_downsample(msfl_handle* h,
                                   const msfl_point* pts, int n, float leaf,
                                   msfl_point* out, int* n_out, msfl_mem mem);
 
+/* The same filter over n_clouds clouds in one pass (the device-resident batch pipeline between
+   msfl_extract_features_batch and msfl_match_scan2map_batch).  Cloud b occupies the region
+   [off[b], off[b+1]) of `pts`; with `idx` it is the points pts[off[b] + idx[off[b] + k]],
+   k < count[b] — exactly how msfl_features_batch lays out its index lists and counts, so a feature
+   list is filtered straight out of the extraction's output.  idx == NULL: the region itself;
+   count == NULL: the whole region.  `off` is a host array (like every batch call), pts / idx /
+   count / out follow `mem`.  The filtered clouds are written back to back into `out` (capacity
+   off[n]-off[0] points) and out_off (HOST, n_clouds+1) receives their boundaries; the call
+   synchronises once to deliver them.  A cloud without a finite point yields no output. */
+msfl_status msfl_voxel_downsample_batch(msfl_handle* h, int n_clouds,
+                                        const msfl_point* pts, const int* idx, const int* off,
+                                        const int* count, float leaf,
+                                        msfl_point* out, int* out_off, msfl_mem mem);
+
 /* TransformPointCloud (laser_mapping.cc:24-31 -> TransformPoint, rigid_transform.h:131-137): every
    point goes f32 -> f64 -> q*p + t -> f32, t (relative time) is carried over.  pose7 is always a
    host array; in == out is allowed. */

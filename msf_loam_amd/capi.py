@@ -21,7 +21,7 @@ EXPORTED = [
     "msfl_set_map", "msfl_match_scan2map", "msfl_match_scan2map_batch", "msfl_match_scan2map_deskew",
     "msfl_associate_scan2map", "msfl_solve_records",
     "msfl_match_scan2scan", "msfl_match_scan2scan_batch", "msfl_extract_features",
-    "msfl_extract_features_batch", "msfl_voxel_downsample", "msfl_transform_cloud",
+    "msfl_extract_features_batch", "msfl_voxel_downsample", "msfl_voxel_downsample_batch", "msfl_transform_cloud",
     "msfl_delta_qp", "msfl_deskew_cloud", "msfl_undistort_cloud",
     "msfl_grid_create", "msfl_grid_destroy", "msfl_grid_insert_scan", "msfl_grid_get_surrounded", "msfl_grid_size", "msfl_grid_dump",
 ]
@@ -360,6 +360,20 @@ class Handle:
         self._check(self.lib.msfl_voxel_downsample(self.h, _vp(pts), C.c_int(len(pts)), C.c_float(leaf), _vp(out),
                                                    C.byref(n_out), C.c_int(MEM_HOST)), "msfl_voxel_downsample")
         return out[:n_out.value].copy()
+
+    def voxel_downsample_batch(self, pts, off, leaf, idx=None, count=None):
+        """Host-memory batch: clouds pts[off[b] (+ idx)] -> (filtered points back to back, out_off (B+1))."""
+        pts = _pts(pts)
+        off = np.ascontiguousarray(off, np.int32)
+        B = len(off) - 1
+        out = np.zeros((max(int(off[-1] - off[0]), 1), 4), np.float32)
+        out_off = np.zeros(B + 1, np.int32)
+        idx_a = None if idx is None else np.ascontiguousarray(idx, np.int32)
+        cnt_a = None if count is None else np.ascontiguousarray(count, np.int32)
+        self._check(self.lib.msfl_voxel_downsample_batch(self.h, C.c_int(B), _vp(pts), _vp(idx_a) if idx_a is not None else None, _vp(off),
+                                                         _vp(cnt_a) if cnt_a is not None else None, C.c_float(leaf), _vp(out), _vp(out_off),
+                                                         C.c_int(MEM_HOST)), "msfl_voxel_downsample_batch")
+        return out[:out_off[-1]].copy(), out_off
 
     def transform_cloud(self, pts, pose7):
         """TransformPointCloud (laser_mapping.cc:24-31)."""

@@ -113,6 +113,7 @@ struct msfl_handle_s {
   DevBuf dk[4];
   DevBuf ex[16];
   DevBuf od[16];
+  DevBuf vb[12];  // batched voxel filter
   DevBuf pp[5];   // per-point passes: pre-integration samples, staged points, dq, dp, flag
 
   PinRing pin;
@@ -442,6 +443,7 @@ void msfl_destroy(msfl_handle* h) {
   for (auto& b : h->ex) b.release();
   for (auto& b : h->od) b.release();
   for (auto& b : h->pp) b.release();
+  for (auto& b : h->vb) b.release();
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }

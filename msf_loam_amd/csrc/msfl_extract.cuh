@@ -536,4 +536,131 @@ __global__ void __launch_bounds__(256) voxel_centroid_kernel(const float4* __res
   out[pos[i] - 1] = make_float4(sx / c, sy / c, sz / c, st / c);
 }
 
+// ---- batched voxel filter: B clouds in one pass (pcl::VoxelGrid per cloud, laser_mapping.cc:264-270) ----
+// Cloud b = count[b] points pts[off[b] + (idx ? idx[off[b] + k] : k)], k < count[b]: the index form
+// reads feature lists straight out of the extraction's output (no gather pass).  Per-cloud bounding
+// box -> (cloud, voxel) keys -> one stable radix sort over the whole batch -> one centroid per key
+// run, accumulated in arrival order with f32 accumulators like the single-cloud kernels above.
+struct VoxelBatchView {
+  const float4* pts; const int* idx; const int* off; const int* count; int n_clouds; int n_total;
+  float inv_leaf;
+};
+struct VoxelCloudDesc { int min_b[3]; int div_b[3]; int n; int bad; };
+
+__device__ __forceinline__ float4 vb_point(const VoxelBatchView& v, int b, int k) {
+  const int o = v.off[b];
+  return v.pts[o + (v.idx ? v.idx[o + k] : k)];
+}
+
+__global__ void __launch_bounds__(256) voxel_batch_desc_kernel(VoxelBatchView v, VoxelCloudDesc* __restrict__ desc, int* __restrict__ out_count) {
+  __shared__ float s_mn[4][3], s_mx[4][3];
+  const int b = blockIdx.x;
+  const int cap = v.off[b + 1] - v.off[b];
+  const int n = v.count ? min(max(v.count[b], 0), cap) : cap;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = threadIdx.x; k < n; k += 256) {
+    const float4 p = vb_point(v, b, k);
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+      mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+      mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o)); }
+  if ((threadIdx.x & 63) == 0)
+    for (int a = 0; a < 3; a++) { s_mn[threadIdx.x >> 6][a] = mn[a]; s_mx[threadIdx.x >> 6][a] = mx[a]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    VoxelCloudDesc d;
+    d.n = n; d.bad = 0;
+    long long cells = 1;
+    for (int a = 0; a < 3; a++) {
+      float lo = s_mn[0][a], hi = s_mx[0][a];
+      for (int w = 1; w < 4; w++) { lo = fminf(lo, s_mn[w][a]); hi = fmaxf(hi, s_mx[w][a]); }
+      if (!(lo <= hi)) { d.min_b[a] = 0; d.div_b[a] = 1; if (n > 0) d.bad = 2; continue; }       // no finite point
+      d.min_b[a] = (int)floorf(lo * v.inv_leaf);
+      d.div_b[a] = (int)floorf(hi * v.inv_leaf) - d.min_b[a] + 1;
+      cells *= d.div_b[a];
+      if (cells > 0x7fffffffLL) d.bad = 1;            // leaf too small for the extent (PCL would skip filtering)
+    }
+    desc[b] = d;
+    out_count[b] = 0;
+  }
+}
+
+// one thread per slot of the concatenated capacity; slots beyond a cloud's count get the last key
+__global__ void __launch_bounds__(256) voxel_batch_key_kernel(VoxelBatchView v, const VoxelCloudDesc* __restrict__ desc,
+                                                               unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= v.n_total) return;
+  const int b = find_scan_off(v.off, v.n_clouds, e + v.off[0]);
+  const int k = e + v.off[0] - v.off[b];
+  const VoxelCloudDesc d = desc[b];
+  unsigned long long key = ~0ull;
+  if (k < d.n && !d.bad) {
+    const float4 p = vb_point(v, b, k);
+    const int i0 = (int)(floorf(p.x * v.inv_leaf) - (float)d.min_b[0]);
+    const int i1 = (int)(floorf(p.y * v.inv_leaf) - (float)d.min_b[1]);
+    const int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)d.min_b[2]);
+    const unsigned long long cell = (unsigned long long)((long long)i0 + (long long)i1 * d.div_b[0] + (long long)i2 * d.div_b[0] * (long long)d.div_b[1]);
+    key = ((unsigned long long)b << 31) | (cell & 0x7fffffffull);
+  }
+  keys[e] = key;
+  vals[e] = (unsigned)e;
+}
+
+__global__ void __launch_bounds__(256) voxel_batch_flag_kernel(const unsigned long long* __restrict__ keys, int n, int* __restrict__ flag,
+                                                                int* __restrict__ out_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = keys[i];
+  const int head = (k != ~0ull && (i == 0 || k != keys[i - 1])) ? 1 : 0;
+  flag[i] = head;
+  if (head) atomicAdd(&out_count[(int)(k >> 31)], 1);
+}
+
+__global__ void __launch_bounds__(256) voxel_batch_centroid_kernel(VoxelBatchView v, const unsigned long long* __restrict__ keys,
+                                                                    const unsigned* __restrict__ vals, const int* __restrict__ flag,
+                                                                    const int* __restrict__ pos, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= v.n_total || !flag[i]) return;
+  const unsigned long long key = keys[i];
+  const int b = (int)(key >> 31);
+  const int base = v.off[b] - v.off[0];
+  float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
+  int j = i;
+  for (; j < v.n_total && keys[j] == key; j++) {
+    const float4 p = vb_point(v, b, (int)vals[j] - base);
+    sx += p.x; sy += p.y; sz += p.z; st += p.w;
+  }
+  const float c = (float)(j - i);
+  out[pos[i] - 1] = make_float4(sx / c, sy / c, sz / c, st / c);
+}
+
+// exclusive scan of the per-cloud voxel counts (B is small: one workgroup, serial per 1024-chunk carry)
+__global__ void __launch_bounds__(1024) voxel_batch_offsets_kernel(const int* __restrict__ cnt, int n, int* __restrict__ off) {
+  __shared__ int s_part[16];
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int c = i < n ? cnt[i] : 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((threadIdx.x & 63) >= o) incl += t; }
+    if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int run = s_carry + incl - c;
+    for (int w = 0; w < (threadIdx.x >> 6); w++) run += s_part[w];
+    if (i < n) off[i] = run;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = run + c;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) off[n] = s_carry;
+}
+
 }  // namespace msfl

@@ -97,3 +97,38 @@ def test_voxel_downsample_matches_oracle(gpu, oracle):
         assert g.shape == o.shape
         assert np.array_equal(g, o), np.abs(g - o).max()
     assert len(gpu.voxel_downsample(np.zeros((0, 4), np.float32), 0.2)) == 0
+
+
+def test_batched_voxel_filter_matches_oracle_per_cloud(gpu, oracle):
+    """msfl_voxel_downsample_batch: plain regions (ragged, one empty) and the index-list form that reads
+    feature lists in the layout msfl_extract_features_batch produces; every cloud bit-for-bit equals
+    the oracle's pcl::VoxelGrid restatement."""
+    rng = np.random.default_rng(17)
+    clouds = []
+    for n in (4000, 0, 1, 2500, 7000):
+        c = np.zeros((n, 4), np.float32)
+        c[:, :3] = rng.uniform(-30, 30, (n, 3)) * np.array([1, 1, 0.1])
+        c[:, 3] = rng.uniform(0, 0.1, n)
+        clouds.append(c)
+    off = np.cumsum([0] + [len(c) for c in clouds]).astype(np.int32)
+    for leaf in (0.2, 0.4, 3.0):
+        out, out_off = gpu.voxel_downsample_batch(np.concatenate(clouds), off, leaf)
+        for b, c in enumerate(clouds):
+            ref = oracle.voxel_grid(c, leaf) if len(c) else np.zeros((0, 4), np.float32)
+            assert np.array_equal(out[out_off[b]:out_off[b + 1]], ref), (leaf, b)
+    # index-list form: cloud b = full[off[b] + idx[off[b] + k]], k < count[b]
+    w, _, _ = common.small_world()
+    scans = [synth.make_scan(w, p, 700 + i) for i, p in enumerate(synth.random_poses(3, 41))]
+    feats = [oracle.extract_features(p, r) for p, r in scans]
+    off = np.cumsum([0] + [len(p) for p, _ in scans]).astype(np.int32)
+    full = np.zeros((off[-1], 4), np.float32)
+    idx = np.zeros(off[-1], np.int32)
+    cnt = np.zeros(3, np.int32)
+    for b, f in enumerate(feats):
+        full[off[b]:off[b] + len(f["full"])] = f["full"]
+        idx[off[b]:off[b] + len(f["less_flat"])] = f["less_flat"]
+        cnt[b] = len(f["less_flat"])
+    out, out_off = gpu.voxel_downsample_batch(full, off, 0.4, idx=idx, count=cnt)
+    for b, f in enumerate(feats):
+        assert np.array_equal(out[out_off[b]:out_off[b + 1]], oracle.voxel_grid(f["full"][f["less_flat"]], 0.4)), b
+    assert np.array_equal(out[out_off[1]:out_off[2]], gpu.voxel_downsample(feats[1]["full"][feats[1]["less_flat"]], 0.4))
