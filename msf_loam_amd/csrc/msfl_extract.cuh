@@ -552,7 +552,9 @@ __device__ __forceinline__ float4 vb_point(const VoxelBatchView& v, int b, int k
   return v.pts[o + (v.idx ? v.idx[o + k] : k)];
 }
 
-__global__ void __launch_bounds__(256) voxel_batch_desc_kernel(VoxelBatchView v, VoxelCloudDesc* __restrict__ desc, int* __restrict__ out_count) {
+// also: n_valid[b] (input to the slot scan) and max_cells[0] = the largest voxel count of any cloud (sort key width)
+__global__ void __launch_bounds__(256) voxel_batch_desc_kernel(VoxelBatchView v, VoxelCloudDesc* __restrict__ desc, int* __restrict__ n_valid,
+                                                                int* __restrict__ max_cells) {
   __shared__ float s_mn[4][3], s_mx[4][3];
   const int b = blockIdx.x;
   const int cap = v.off[b + 1] - v.off[b];
@@ -586,57 +588,58 @@ __global__ void __launch_bounds__(256) voxel_batch_desc_kernel(VoxelBatchView v,
       if (cells > 0x7fffffffLL) d.bad = 1;            // leaf too small for the extent (PCL would skip filtering)
     }
     desc[b] = d;
-    out_count[b] = 0;
+    n_valid[b] = d.bad ? 0 : n;
+    if (!d.bad && n > 0) atomicMax(max_cells, (int)cells);
   }
 }
 
-// one thread per slot of the concatenated capacity; slots beyond a cloud's count get the last key
+// one thread per VALID point of the batch: slot e of the compacted numbering belongs to cloud
+// b = upper_bound(in_off, e) - 1 at position k = e - in_off[b]
 __global__ void __launch_bounds__(256) voxel_batch_key_kernel(VoxelBatchView v, const VoxelCloudDesc* __restrict__ desc,
+                                                               const int* __restrict__ in_off, int n_valid, int cell_bits,
                                                                unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= v.n_total) return;
-  const int b = find_scan_off(v.off, v.n_clouds, e + v.off[0]);
-  const int k = e + v.off[0] - v.off[b];
+  if (e >= n_valid) return;
+  const int b = find_scan_off(in_off, v.n_clouds, e);
+  const int k = e - in_off[b];
   const VoxelCloudDesc d = desc[b];
-  unsigned long long key = ~0ull;
-  if (k < d.n && !d.bad) {
-    const float4 p = vb_point(v, b, k);
-    const int i0 = (int)(floorf(p.x * v.inv_leaf) - (float)d.min_b[0]);
-    const int i1 = (int)(floorf(p.y * v.inv_leaf) - (float)d.min_b[1]);
-    const int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)d.min_b[2]);
-    const unsigned long long cell = (unsigned long long)((long long)i0 + (long long)i1 * d.div_b[0] + (long long)i2 * d.div_b[0] * (long long)d.div_b[1]);
-    key = ((unsigned long long)b << 31) | (cell & 0x7fffffffull);
-  }
-  keys[e] = key;
-  vals[e] = (unsigned)e;
+  const float4 p = vb_point(v, b, k);
+  const int i0 = (int)(floorf(p.x * v.inv_leaf) - (float)d.min_b[0]);
+  const int i1 = (int)(floorf(p.y * v.inv_leaf) - (float)d.min_b[1]);
+  const int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)d.min_b[2]);
+  const unsigned long long cell = (unsigned long long)((long long)i0 + (long long)i1 * d.div_b[0] + (long long)i2 * d.div_b[0] * (long long)d.div_b[1]);
+  keys[e] = ((unsigned long long)b << cell_bits) | (cell & ((1ull << cell_bits) - 1ull));
+  vals[e] = (unsigned)k;
 }
 
-__global__ void __launch_bounds__(256) voxel_batch_flag_kernel(const unsigned long long* __restrict__ keys, int n, int* __restrict__ flag,
-                                                                int* __restrict__ out_count) {
+__global__ void __launch_bounds__(256) voxel_batch_flag_kernel(const unsigned long long* __restrict__ keys, int n, int* __restrict__ flag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const unsigned long long k = keys[i];
-  const int head = (k != ~0ull && (i == 0 || k != keys[i - 1])) ? 1 : 0;
-  flag[i] = head;
-  if (head) atomicAdd(&out_count[(int)(k >> 31)], 1);
+  flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
 
+// one thread per voxel head: centroid of the run in arrival order; the head that opens a cloud also
+// publishes the output boundaries of every cloud since the previous non-empty one
 __global__ void __launch_bounds__(256) voxel_batch_centroid_kernel(VoxelBatchView v, const unsigned long long* __restrict__ keys,
                                                                     const unsigned* __restrict__ vals, const int* __restrict__ flag,
-                                                                    const int* __restrict__ pos, float4* __restrict__ out) {
+                                                                    const int* __restrict__ pos, int n, int cell_bits,
+                                                                    float4* __restrict__ out, int* __restrict__ out_off) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= v.n_total || !flag[i]) return;
+  if (i >= n || !flag[i]) return;
   const unsigned long long key = keys[i];
-  const int b = (int)(key >> 31);
-  const int base = v.off[b] - v.off[0];
+  const int b = (int)(key >> cell_bits);
   float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
   int j = i;
-  for (; j < v.n_total && keys[j] == key; j++) {
-    const float4 p = vb_point(v, b, (int)vals[j] - base);
+  for (; j < n && keys[j] == key; j++) {
+    const float4 p = vb_point(v, b, (int)vals[j]);
     sx += p.x; sy += p.y; sz += p.z; st += p.w;
   }
   const float c = (float)(j - i);
-  out[pos[i] - 1] = make_float4(sx / c, sy / c, sz / c, st / c);
+  const int o = pos[i] - 1;
+  out[o] = make_float4(sx / c, sy / c, sz / c, st / c);
+  const int prev = i == 0 ? -1 : (int)(keys[i - 1] >> cell_bits);
+  for (int cl = prev + 1; cl <= b; cl++) out_off[cl] = o;                 // empty clouds in between start (and end) here
+  if (j == n) { const int total = pos[n - 1]; for (int cl = b + 1; cl <= v.n_clouds; cl++) out_off[cl] = total; }
 }
 
 // exclusive scan of the per-cloud voxel counts (B is small: one workgroup, serial per 1024-chunk carry)
