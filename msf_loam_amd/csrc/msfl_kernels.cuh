@@ -174,6 +174,9 @@ __device__ __forceinline__ void top5_init(Top5& t) { t.k0 = t.k1 = t.k2 = t.k3 =
 __device__ __forceinline__ float top5_d4(const Top5& t) { return __uint_as_float((unsigned int)(t.k4 >> 32)); }  // NaN while < 5 found
 
 __device__ __forceinline__ void top5_insert(Top5& t, float d, int idx) {
+  // cheap pre-filter on the distance word alone (a full-rate 32-bit compare; the bit pattern of a
+  // non-negative float is monotone), then the exact 64-bit (distance, index) order
+  if (__float_as_uint(d) > (unsigned int)(t.k4 >> 32)) return;
   const unsigned long long x = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)idx;
   if (!(x < t.k4)) return;
   const bool c3 = x < t.k3, c2 = x < t.k2, c1 = x < t.k1, c0 = x < t.k0;
@@ -189,6 +192,18 @@ __device__ __forceinline__ float l2_simple(float4 a, float3 q) {
   const float dx = a.x - q.x, dy = a.y - q.y, dz = a.z - q.z;
   float r = dx * dx;
   r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+// the same arithmetic with x and y in one packed-f32 lane pair (v_pk_add_f32 / v_pk_mul_f32: two
+// IEEE operations per instruction, individually rounded, so the result is bit-identical)
+typedef float msfl_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float l2_simple_pk(float4 a, msfl_f2 qxy, float qz) {
+  const msfl_f2 axy = {a.x, a.y};
+  const msfl_f2 dxy = axy - qxy;
+  const msfl_f2 sxy = dxy * dxy;
+  const float dz = a.z - qz;
+  float r = sxy.x + sxy.y;
   r = r + dz * dz;
   return r;
 }
@@ -219,6 +234,7 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
   const float gz0 = axis_gap(uz, cz - 1), gz1 = axis_gap(uz, cz), gz2 = axis_gap(uz, cz + 1);
   const float gxa = axis_gap(ux, xs), gxb = axis_gap(ux, xe);
   const float gxa2 = gxa * gxa * cell2, gxb2 = gxb * gxb * cell2;
+  const msfl_f2 qxy = {q.x, q.y};
   // visit order of the 9 (dy,dz) rows: centre, 4 edge neighbours, 4 diagonal neighbours.
   // Fully unrolled: offsets are compile-time constants.
   constexpr int DYS[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
@@ -239,13 +255,18 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
     const int row = (z * g.dy + y) * g.dx;
     // x-adjacent cells are contiguous in the sorted array: one range per (y, z)
     const int s = cell_start[row + a], e = cell_start[row + b + 1];
-    int k = s;
-    for (; k + 1 < e; k += 2) {            // two loads in flight
-      const float4 m0 = sorted[k], m1 = sorted[k + 1];
-      top5_insert(t, l2_simple(m0, q), __float_as_int(m0.w));
-      top5_insert(t, l2_simple(m1, q), __float_as_int(m1.w));
+    const float4* p = sorted + s;
+    const float4* const pe = sorted + e;
+    for (; p + 1 < pe; p += 2) {            // two loads in flight, one address register
+      float4 m0 = p[0], m1 = p[1];
+      // keep the index word in the 16-byte load: left alone, the compiler splits it off into a second,
+      // dependent load inside the (latency-critical) insertion path
+      asm volatile("" : "+v"(m0.w));
+      top5_insert(t, l2_simple_pk(m0, qxy, q.z), __float_as_int(m0.w));
+      asm volatile("" : "+v"(m1.w));
+      top5_insert(t, l2_simple_pk(m1, qxy, q.z), __float_as_int(m1.w));
     }
-    if (k < e) { const float4 m = sorted[k]; top5_insert(t, l2_simple(m, q), __float_as_int(m.w)); }
+    if (p < pe) { float4 m = p[0]; asm volatile("" : "+v"(m.w)); top5_insert(t, l2_simple_pk(m, qxy, q.z), __float_as_int(m.w)); }
   }
 }
 
