@@ -25,9 +25,16 @@ namespace msfl {
 // of a query contains every map point whose f32 distance can pass the reference's
 // `pointSearchSqDis[4] < 1.0` gate: exact-kNN-equivalent on every ACCEPTED query.
 // ---------------------------------------------------------------------------------------------
+#ifndef MSFL_GRID_XSUB
+#define MSFL_GRID_XSUB 2
+#endif
+constexpr int kGridXSub = MSFL_GRID_XSUB;
+
 struct GridDesc {
   float ox, oy, oz;   // origin = bbox min
-  float inv_cell;
+  float inv_cell;     // 1 / cell edge in y and z
+  float inv_cell_x;   // cells are kGridXSub times finer along x (the fastest index): a (y,z) row of 2*kGridXSub+1 cells
+                      // is still ONE contiguous range, but its ends can be trimmed in finer steps
   int dx, dy, dz;
   int n_pts;          // finite points indexed
   int n_cells;
@@ -92,7 +99,7 @@ __global__ void grid_setup_kernel(const int* __restrict__ bbox, double radius, i
   GridDesc g;
   g.n_pts = 0; g.reach = 1;
   if (bbox[0] == 0x7fffffff) {            // no finite point
-    g.ox = g.oy = g.oz = 0.f; g.inv_cell = 1.f; g.dx = g.dy = g.dz = 1; g.n_cells = 1; g.want_cells = 1;
+    g.ox = g.oy = g.oz = 0.f; g.inv_cell = 1.f; g.inv_cell_x = (float)kGridXSub; g.dx = g.dy = g.dz = 1; g.n_cells = 1; g.want_cells = 1;
     *out = g;
     return;
   }
@@ -105,7 +112,8 @@ __global__ void grid_setup_kernel(const int* __restrict__ bbox, double radius, i
   for (;;) {
     double total = 1.0;
     for (int a = 0; a < 3; a++) {
-      dims[a] = (int)floor(((double)mx[a] - (double)mn[a]) / cell) + 2;   // +1 spare cell: f32 rounding of (v-o)*inv
+      const double edge = a == 0 ? cell / kGridXSub : cell;
+      dims[a] = (int)floor(((double)mx[a] - (double)mn[a]) / edge) + 2;   // +1 spare cell: f32 rounding of (v-o)*inv
       if (dims[a] < 2) dims[a] = 2;
       total *= dims[a];
     }
@@ -115,6 +123,7 @@ __global__ void grid_setup_kernel(const int* __restrict__ bbox, double radius, i
   }
   g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
   g.inv_cell = (float)(1.0 / cell);
+  g.inv_cell_x = (float)((double)kGridXSub / cell);
   g.dx = dims[0]; g.dy = dims[1]; g.dz = dims[2];
   g.n_cells = g.dx * g.dy * g.dz;
   *out = g;
@@ -128,7 +137,7 @@ __global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restric
   const float4 p = pts[i];
   int c = -1;
   if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-    int cx = grid_coord(p.x, g.ox, g.inv_cell, g.dx); cx = min(max(cx, 0), g.dx - 1);
+    int cx = grid_coord(p.x, g.ox, g.inv_cell_x, g.dx); cx = min(max(cx, 0), g.dx - 1);
     int cy = grid_coord(p.y, g.oy, g.inv_cell, g.dy); cy = min(max(cy, 0), g.dy - 1);
     int cz = grid_coord(p.z, g.oz, g.inv_cell, g.dz); cz = min(max(cz, 0), g.dz - 1);
     c = (cz * g.dy + cy) * g.dx + cx;
@@ -221,39 +230,26 @@ __device__ __forceinline__ float axis_gap(float u, int c) {
 __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __restrict__ sorted,
                                           const int* __restrict__ cell_start, float3 q, Top5& t) {
   top5_init(t);
-  const float ux = (q.x - g.ox) * g.inv_cell, uy = (q.y - g.oy) * g.inv_cell, uz = (q.z - g.oz) * g.inv_cell;
-  const int cx = grid_coord(q.x, g.ox, g.inv_cell, g.dx);
+  const float ux = (q.x - g.ox) * g.inv_cell_x, uy = (q.y - g.oy) * g.inv_cell, uz = (q.z - g.oz) * g.inv_cell;
+  const int cx = grid_coord(q.x, g.ox, g.inv_cell_x, g.dx);
   const int cy = grid_coord(q.y, g.oy, g.inv_cell, g.dy);
   const int cz = grid_coord(q.z, g.oz, g.inv_cell, g.dz);
-  const int xs = max(cx - 1, 0), xe = min(cx + 1, g.dx - 1);
+  const int xs = max(cx - kGridXSub, 0), xe = min(cx + kGridXSub, g.dx - 1);
   if (xs > xe) return;
   const float cell = 1.0f / g.inv_cell;
   const float cell2 = cell * cell;
   // per-axis lower bounds for the three y and three z cell offsets, computed once
   const float gy0 = axis_gap(uy, cy - 1), gy1 = axis_gap(uy, cy), gy2 = axis_gap(uy, cy + 1);
   const float gz0 = axis_gap(uz, cz - 1), gz1 = axis_gap(uz, cz), gz2 = axis_gap(uz, cz + 1);
-  const float gxa = axis_gap(ux, xs), gxb = axis_gap(ux, xe);
-  const float gxa2 = gxa * gxa * cell2, gxb2 = gxb * gxb * cell2;
+  const float cellx = 1.0f / g.inv_cell_x;
+  const float cellx2 = cellx * cellx;
   const msfl_f2 qxy = {q.x, q.y};
   // visit order of the 9 (dy,dz) rows: centre, 4 edge neighbours, 4 diagonal neighbours.
   // Fully unrolled: offsets are compile-time constants.
   constexpr int DYS[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
   constexpr int DZS[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
-#pragma unroll
-  for (int r = 0; r < 9; r++) {
-    const int y = cy + DYS[r], z = cz + DZS[r];
-    if (y < 0 || y >= g.dy || z < 0 || z >= g.dz) continue;
-    const float gy = DYS[r] < 0 ? gy0 : (DYS[r] == 0 ? gy1 : gy2);
-    const float gz = DZS[r] < 0 ? gz0 : (DZS[r] == 0 ? gz1 : gz2);
-    const float row2 = (gy * gy + gz * gz) * cell2;
-    const float d4 = top5_d4(t);
-    if (row2 > d4) continue;                  // NaN (fewer than 5 found so far) never prunes
-    // trim the x range: drop an end cell whose lower bound exceeds the 5th-best distance
-    int a = xs, b = xe;
-    if (a < b && row2 + gxa2 > d4) a++;
-    if (a < b && row2 + gxb2 > d4) b--;
-    const int row = (z * g.dy + y) * g.dx;
-    // x-adjacent cells are contiguous in the sorted array: one range per (y, z)
+  // candidates of the cells [a, b] of a row: x-adjacent cells are contiguous in the sorted array
+  auto scan = [&](int row, int a, int b) __attribute__((always_inline)) {
     const int s = cell_start[row + a], e = cell_start[row + b + 1];
     const float4* p = sorted + s;
     const float4* const pe = sorted + e;
@@ -267,6 +263,26 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
       top5_insert(t, l2_simple_pk(m1, qxy, q.z), __float_as_int(m1.w));
     }
     if (p < pe) { float4 m = p[0]; asm volatile("" : "+v"(m.w)); top5_insert(t, l2_simple_pk(m, qxy, q.z), __float_as_int(m.w)); }
+  };
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const int y = cy + DYS[r], z = cz + DZS[r];
+    if (y < 0 || y >= g.dy || z < 0 || z >= g.dz) continue;
+    const float gy = DYS[r] < 0 ? gy0 : (DYS[r] == 0 ? gy1 : gy2);
+    const float gz = DZS[r] < 0 ? gz0 : (DZS[r] == 0 ? gz1 : gz2);
+    const float row2 = (gy * gy + gz * gz) * cell2;
+    const int row = (z * g.dy + y) * g.dx;
+    const float d4 = top5_d4(t);
+    if (row2 > d4) continue;                  // NaN (fewer than 5 found so far) never prunes
+    // trim the x range: drop end cells whose lower bound exceeds the 5th-best distance
+    int a = xs, b = xe;
+#pragma unroll
+    for (int k = 0; k < kGridXSub; k++) {
+      const float ga = axis_gap(ux, a), gb = axis_gap(ux, b);
+      if (a < b && row2 + ga * ga * cellx2 > d4) a++;
+      if (a < b && row2 + gb * gb * cellx2 > d4) b--;
+    }
+    scan(row, a, b);
   }
 }
 
