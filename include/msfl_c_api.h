@@ -153,6 +153,8 @@ const char* msfl_status_string(int status);
 /* Human-readable detail of the last non-OK status on this handle ("" if none). */
 const char* msfl_last_error(const msfl_handle* h);
 
+/* enabled: 0 off; 1 every kernel class; 2 only the association (5-NN) kernel — two events per launch
+   instead of two per class, for timing the dominant kernel inside a throughput measurement. */
 msfl_status msfl_set_timing(msfl_handle* h, int enabled);
 msfl_status msfl_get_timing(msfl_handle* h, msfl_timing* out, int reset);
 

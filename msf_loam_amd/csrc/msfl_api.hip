@@ -119,7 +119,7 @@ struct msfl_handle_s {
   PinRing pin;
 
   // timing
-  bool timing = false;
+  int timing = 0;            // 0 off, 1 every kernel class, 2 the association (5-NN) kernel only
   std::vector<TimedSpan> spans;
   std::vector<hipEvent_t> free_events;
   double t_ms[T_COUNT] = {0};
@@ -149,7 +149,7 @@ hipEvent_t get_event(msfl_handle* h) {
 
 struct ScopedTimer {
   msfl_handle* h; TimedSpan s{}; bool on;
-  ScopedTimer(msfl_handle* h_, int cls) : h(h_), on(h_->timing) {
+  ScopedTimer(msfl_handle* h_, int cls) : h(h_), on(h_->timing == 1 || (h_->timing == 2 && cls == T_ASSOC)) {
     if (on) { s.a = get_event(h); s.b = get_event(h); s.cls = cls; (void)hipEventRecord(s.a, h->stream); }
   }
   ~ScopedTimer() {
@@ -486,7 +486,7 @@ const char* msfl_last_error(const msfl_handle* h) { return h ? h->last_error.c_s
 
 msfl_status msfl_set_timing(msfl_handle* h, int enabled) {
   msfl_status s = enter(h); if (s) return s;
-  h->timing = enabled != 0;
+  h->timing = enabled < 0 ? 0 : (enabled > 2 ? 1 : enabled);
   return MSFL_OK;
 }
 

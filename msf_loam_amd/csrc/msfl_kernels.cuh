@@ -427,8 +427,11 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
 // K4b: 5 neighbours -> line fit (3x3 Jacobi eigen) / plane fit (5x3 Householder QR) -> record.
 // Edge: {C, N}.  Plane: {N, N.C} (the residual N.(Rp+t-C) only needs the offset N.C).
 // `full` (optional, debug/parity API) receives {C, N} for every feature.
+#ifndef MSFL_FIT_WAVES
+#define MSFL_FIT_WAVES 1
+#endif
 template <bool DESKEW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, MSFL_FIT_WAVES)
 fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
                     const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
                     double* __restrict__ rec, double* __restrict__ full) {
