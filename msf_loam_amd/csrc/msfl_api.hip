@@ -80,6 +80,7 @@ struct PinRing {
 
 struct MapIndex {
   DevBuf gdesc;        // GridDesc, computed on the device (no host round trip in msfl_set_map)
+  DevBuf bbox;         // 6 ordered ints, armed once and re-armed by grid_setup_kernel
   int cap_cells = 0;   // capacity of cell_start / count (cells)
   // feedback for the table span of the next build (asynchronous read-back, never waited for)
   int* want_host = nullptr; hipEvent_t want_ev = nullptr; bool want_pending = false; int span = 0;
@@ -110,6 +111,7 @@ struct msfl_handle_s {
   // scratch
   DevBuf in_corner, in_surf, in_off, poses, status, info, records, pprime, nn;
   DevBuf idx_cell_of, idx_count, idx_bbox, idx_cub, idx_stage;
+  size_t idx_count_zero = 0;   // leading ints of idx_count known to be zero on the stream
   DevBuf dk[4];
   DevBuf ex[16];
   DevBuf od[16];
@@ -211,25 +213,33 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   if (mi.span <= 0) mi.span = std::min(1 << 20, h->grid_cap_cells);
   const int cap = mi.span;
   HIPCHK(h, mi.gdesc.reserve(sizeof(GridDesc)));
-  HIPCHK(h, h->idx_bbox.reserve(6 * sizeof(int)));
   HIPCHK(h, h->idx_cell_of.reserve(std::max<size_t>(1, (size_t)n) * sizeof(int)));
+  const void* count_before = h->idx_count.p;
   HIPCHK(h, h->idx_count.reserve(((size_t)cap + 1) * sizeof(int)));
+  if (h->idx_count.p != count_before) h->idx_count_zero = 0;
   HIPCHK(h, mi.cell_start.reserve(((size_t)cap + 1) * sizeof(int)));
   HIPCHK(h, mi.sorted.reserve(std::max<size_t>(1, (size_t)n) * sizeof(float4)));
   HIPCHK(h, mi.pos_of.reserve(std::max<size_t>(1, (size_t)n) * sizeof(int)));
   mi.cap_cells = cap;
-  const int init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
-  HIPCHK(h, h->pin.upload(h->idx_bbox.p, init, sizeof(init), st));
+  if (!mi.bbox.p) {                       // armed once; grid_setup_kernel re-arms it after every read
+    HIPCHK(h, mi.bbox.reserve(6 * sizeof(int)));
+    const int init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
+    HIPCHK(h, h->pin.upload(mi.bbox.p, init, sizeof(init), st));
+  }
   if (n > 0) {
     const int blocks = std::min(div_up(n, 256), 64);   // few blocks: the 6 atomics per wave contend on one line
-    hipLaunchKernelGGL(grid_bbox_kernel, dim3(blocks), dim3(256), 0, st, pts, n, h->idx_bbox.as<int>());
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(blocks), dim3(256), 0, st, pts, n, mi.bbox.as<int>());
   }
-  hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1), 0, st, (const int*)h->idx_bbox.as<int>(),
+  hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1), 0, st, mi.bbox.as<int>(),
                      std::sqrt((double)h->prm.map_knn_max_sq_dist), cap, mi.gdesc.as<GridDesc>());
   // the table is cleared / scanned over the cells actually used last time (+ margin) when known,
   // else over the full capacity; the device never indexes beyond n_cells <= cap.
   const size_t span = (size_t)cap + 1;
-  HIPCHK(h, hipMemsetAsync(h->idx_count.p, 0, span * sizeof(int), st));
+  // the scatter kernel counts every cell back down to zero, so the table only needs clearing when it
+  // is new or larger than what has been cleared before
+  const size_t zeroed = h->idx_count_zero;
+  h->idx_count_zero = 0;                  // unknown until this build has been enqueued completely
+  if (span > zeroed) HIPCHK(h, hipMemsetAsync(h->idx_count.p, 0, span * sizeof(int), st));
   if (n > 0)
     hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, (const GridDesc*)mi.gdesc.as<GridDesc>(),
                        h->idx_cell_of.as<int>(), h->idx_count.as<int>());
@@ -239,9 +249,10 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(h->idx_cub.p, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(), (int)span, st));
   if (n > 0)
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, h->idx_cell_of.as<int>(),
-                       mi.cell_start.as<int>(), h->idx_count.as<int>(), mi.sorted.as<float4>(), mi.pos_of.as<int>());
-  hipLaunchKernelGGL(grid_finalize_kernel, dim3(1), dim3(1), 0, st, (const int*)mi.cell_start.as<int>(), mi.gdesc.as<GridDesc>());
+                       mi.cell_start.as<int>(), h->idx_count.as<int>(), mi.sorted.as<float4>(), mi.pos_of.as<int>(),
+                       mi.gdesc.as<GridDesc>());
   HIPCHK(h, hipGetLastError());
+  h->idx_count_zero = std::max(zeroed, span);
   if (!mi.want_pending) {
     HIPCHK(h, hipMemcpyAsync(mi.want_host, &mi.gdesc.as<GridDesc>()->want_cells, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipEventRecord(mi.want_ev, st));
@@ -435,7 +446,7 @@ void msfl_destroy(msfl_handle* h) {
     if (mi->want_host) (void)hipHostFree(mi->want_host);
   }
   DevBuf* bufs[] = {&h->map_c.sorted, &h->map_c.cell_start, &h->map_s.sorted, &h->map_s.cell_start, &h->map_c.pos_of, &h->map_s.pos_of,
-                    &h->map_c.gdesc, &h->map_s.gdesc, &h->in_corner,
+                    &h->map_c.gdesc, &h->map_s.gdesc, &h->map_c.bbox, &h->map_s.bbox, &h->in_corner,
                     &h->in_surf, &h->in_off, &h->poses, &h->status, &h->info, &h->records, &h->pprime, &h->nn,
                     &h->idx_cell_of, &h->idx_count, &h->idx_bbox, &h->idx_cub, &h->idx_stage};
   for (auto* b : bufs) b->release();

@@ -95,16 +95,19 @@ __device__ __forceinline__ int grid_coord(float v, float o, float inv, int dim) 
 // One thread: bbox -> grid descriptor, entirely on the device so that msfl_set_map needs no host
 // round trip.  Cell edge = 1.001 * acceptance radius, grown by 26 % steps until the dense table fits
 // `cap_cells` (larger cells stay exact).  An empty cloud yields n_cells = 1, n_pts = 0.
-__global__ void grid_setup_kernel(const int* __restrict__ bbox, double radius, int cap_cells, GridDesc* __restrict__ out) {
+// `bbox` is re-armed (INT_MAX / INT_MIN) for the next build once it has been read.
+__global__ void grid_setup_kernel(int* __restrict__ bbox, double radius, int cap_cells, GridDesc* __restrict__ out) {
   GridDesc g;
+  const int b0 = bbox[0];
   g.n_pts = 0; g.reach = 1;
-  if (bbox[0] == 0x7fffffff) {            // no finite point
+  if (b0 == 0x7fffffff) {            // no finite point
     g.ox = g.oy = g.oz = 0.f; g.inv_cell = 1.f; g.inv_cell_x = (float)kGridXSub; g.dx = g.dy = g.dz = 1; g.n_cells = 1; g.want_cells = 1;
     *out = g;
     return;
   }
   float mn[3], mx[3];
   for (int a = 0; a < 3; a++) { mn[a] = ordered_to_float(bbox[a]); mx[a] = ordered_to_float(bbox[3 + a]); }
+  for (int a = 0; a < 3; a++) { bbox[a] = 0x7fffffff; bbox[3 + a] = (int)0x80000000; }
   double cell = 1.001 * radius;
   int dims[3];
   bool first = true;
@@ -146,18 +149,16 @@ __global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restric
   cell_of[i] = c;
 }
 
-// after the exclusive scan: number of indexed (finite) points = cell_start[n_cells]
-__global__ void grid_finalize_kernel(const int* __restrict__ cell_start, GridDesc* __restrict__ g) {
-  g->n_pts = cell_start[g->n_cells];
-}
-
-// cursor[] holds the per-cell counts on entry and is consumed; the order inside a cell is
-// arbitrary, which is harmless because the kNN selection uses the total order (d2, original index).
+// cursor[] holds the per-cell counts on entry and is consumed — it is all zeros again afterwards, so
+// the next build needs no memset; the order inside a cell is arbitrary, which is harmless because
+// the kNN selection uses the total order (d2, original index).
 __global__ void __launch_bounds__(256) grid_scatter_kernel(const float4* __restrict__ pts, int n,
                                                             const int* __restrict__ cell_of,
                                                             const int* __restrict__ cell_start, int* __restrict__ cursor,
-                                                            float4* __restrict__ sorted, int* __restrict__ pos_of) {
+                                                            float4* __restrict__ sorted, int* __restrict__ pos_of,
+                                                            GridDesc* __restrict__ g) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) g->n_pts = cell_start[g->n_cells];     // number of indexed (finite) points
   if (i >= n) return;
   const int c = cell_of[i];
   if (c < 0) { pos_of[i] = -1; return; }
