@@ -54,19 +54,29 @@ def build_inputs(B, map_points, seed_offset, extractor=None):
 
 def product_extractor(handle):
     """Feature clouds through the product's own GPU path: msfl_extract_features_batch +
-    msfl_voxel_downsample (0.2 m corner / 0.4 m surf, laser_mapping.cc:264-270)."""
+    msfl_voxel_downsample_batch (0.2 m corner / 0.4 m surf, laser_mapping.cc:264-270), 256 scans per call."""
     def run(raw):
         out = []
-        chunk = 64
+        chunk = 256
         for s in range(0, len(raw), chunk):
             part = raw[s:s + chunk]
             pts = np.concatenate([p for p, _, _ in part])
             ring = np.concatenate([r for _, r, _ in part])
             off = np.cumsum([0] + [len(p) for p, _, _ in part]).astype(np.int32)
-            for f in handle.extract_features_batch(pts, ring, off):
-                c = handle.voxel_downsample(f["full"][f["less_sharp"]], 0.2)
-                sf = handle.voxel_downsample(f["full"][f["less_flat"]], 0.4)
-                out.append((c, sf))
+            feats = handle.extract_features_batch(pts, ring, off)
+            # the layout msfl_features_batch uses on the device: per-scan regions at the input offsets
+            full = np.zeros((off[-1], 4), np.float32)
+            idx = {k: np.zeros(off[-1], np.int32) for k in ("less_sharp", "less_flat")}
+            cnt = {k: np.zeros(len(part), np.int32) for k in ("less_sharp", "less_flat")}
+            for b, f in enumerate(feats):
+                full[off[b]:off[b] + len(f["full"])] = f["full"]
+                for k in idx:
+                    idx[k][off[b]:off[b] + len(f[k])] = f[k]
+                    cnt[k][b] = len(f[k])
+            c, c_off = handle.voxel_downsample_batch(full, off, 0.2, idx=idx["less_sharp"], count=cnt["less_sharp"])
+            sf, s_off = handle.voxel_downsample_batch(full, off, 0.4, idx=idx["less_flat"], count=cnt["less_flat"])
+            for b in range(len(part)):
+                out.append((c[c_off[b]:c_off[b + 1]], sf[s_off[b]:s_off[b + 1]]))
         return out
     return run
 
