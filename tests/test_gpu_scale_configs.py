@@ -58,3 +58,34 @@ def test_dense_2m_point_map(gpu, oracle):
     rec = gpu.associate_scan2map(corner, surf, guess)
     corr = oracle.associate_scan2map(mc, far, corner, surf, guess)
     assert np.array_equal(np.any(rec[:, 3:] != 0, axis=1), corr["kind"] != 0)
+
+
+def test_full_bench_batch_properties(gpu, oracle):
+    """BASELINE configs[1] at full size (1024 VLP-16 scans, 200 k-point map) through size-independent
+    properties: registrations are independent units, so the batch is invariant under a permutation of
+    its scans and bit-reproducible; every scan converges to its true pose; a sample agrees with the
+    oracle far inside the 1e-4 m / 1e-4 rad bar."""
+    import bench
+    B = 1024
+    inp = bench.build_inputs(B, 200000, 0, extractor=bench.product_extractor(gpu))
+    gpu.set_map(inp["map_corner"], inp["map_surf"])
+    co, so = inp["corner_off"], inp["surf_off"]
+    poses, status, _ = gpu.match_scan2map_batch(inp["corner"], co, inp["surf"], so, inp["guesses"])
+    assert np.all(status == 0)
+    again, _, _ = gpu.match_scan2map_batch(inp["corner"], co, inp["surf"], so, inp["guesses"])
+    assert np.array_equal(poses, again), "bit-reproducible"
+    # reversed order of the scans
+    perm = np.arange(B)[::-1]
+    c_parts = [inp["corner"][co[b]:co[b + 1]] for b in perm]
+    s_parts = [inp["surf"][so[b]:so[b + 1]] for b in perm]
+    co2 = np.cumsum([0] + [len(x) for x in c_parts]).astype(np.int32)
+    so2 = np.cumsum([0] + [len(x) for x in s_parts]).astype(np.int32)
+    rev, st2, _ = gpu.match_scan2map_batch(np.concatenate(c_parts), co2, np.concatenate(s_parts), so2, inp["guesses"][perm])
+    assert np.all(st2 == 0) and np.array_equal(rev[::-1], poses), "a registration does not depend on its neighbours in the batch"
+    err = np.array([synth.pose_error(poses[b], inp["truth"][b]) for b in range(B)])
+    assert err[:, 0].max() < 0.05 and err[:, 1].max() < 0.01
+    for b in (0, 333, 1023):
+        rc, po, _ = oracle.match_scan2map(inp["map_corner"], inp["map_surf"], inp["corner"][co[b]:co[b + 1]],
+                                          inp["surf"][so[b]:so[b + 1]], inp["guesses"][b])
+        dt, dr = synth.pose_error(poses[b], po)
+        assert rc == 0 and dt < 1e-7 and dr < 1e-7
