@@ -180,8 +180,14 @@ struct Top5 {
   unsigned long long k0, k1, k2, k3, k4;
 };
 
-__device__ __forceinline__ void top5_init(Top5& t) { t.k0 = t.k1 = t.k2 = t.k3 = t.k4 = ~0ull; }
-__device__ __forceinline__ float top5_d4(const Top5& t) { return __uint_as_float((unsigned int)(t.k4 >> 32)); }  // NaN while < 5 found
+// Every slot starts at (bound, 0xffffffff): a result is only ACCEPTED when its 5th distance is below the
+// reference's gate (< 1.0, mapping_scan_matcher.cc:128,198), so candidates at or beyond the gate can be
+// dropped at the pre-filter and rows / end cells farther than it pruned from the first row on.  A query
+// with fewer than five neighbours inside the gate keeps the sentinel in k4 and is rejected.
+__device__ __forceinline__ void top5_init(Top5& t, float bound) {
+  t.k0 = t.k1 = t.k2 = t.k3 = t.k4 = ((unsigned long long)__float_as_uint(bound) << 32) | 0xffffffffull;
+}
+__device__ __forceinline__ float top5_d4(const Top5& t) { return __uint_as_float((unsigned int)(t.k4 >> 32)); }  // the gate while < 5 found
 
 __device__ __forceinline__ void top5_insert(Top5& t, float d, int idx) {
   // cheap pre-filter on the distance word alone (a full-rate 32-bit compare; the bit pattern of a
@@ -229,8 +235,8 @@ __device__ __forceinline__ float axis_gap(float u, int c) {
 }
 
 __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __restrict__ sorted,
-                                          const int* __restrict__ cell_start, float3 q, Top5& t) {
-  top5_init(t);
+                                          const int* __restrict__ cell_start, float3 q, float max_sq_dist, Top5& t) {
+  top5_init(t, max_sq_dist);
   const float ux = (q.x - g.ox) * g.inv_cell_x, uy = (q.y - g.oy) * g.inv_cell, uz = (q.z - g.oz) * g.inv_cell;
   const int cx = grid_coord(q.x, g.ox, g.inv_cell_x, g.dx);
   const int cy = grid_coord(q.y, g.oy, g.inv_cell, g.dy);
@@ -274,7 +280,7 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
     const float row2 = (gy * gy + gz * gz) * cell2;
     const int row = (z * g.dy + y) * g.dx;
     const float d4 = top5_d4(t);
-    if (row2 > d4) continue;                  // NaN (fewer than 5 found so far) never prunes
+    if (row2 > d4) continue;                  // d4 is the acceptance gate until five neighbours are known
     // trim the x range: drop end cells whose lower bound exceeds the 5th-best distance
     int a = xs, b = xe;
 #pragma unroll
@@ -412,9 +418,9 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
     q = transform_point_f32(T, f.x, f.y, f.z);                          // :123 / :193
   }
   Top5 t;
-  if (is_edge) { const GridDesc gc = *gcp; knn5_grid(gc, map_c, cs_c, q, t); }
-  else { const GridDesc gs = *gsp; knn5_grid(gs, map_s, cs_s, q, t); }
-  if (t.k4 != ~0ull && (double)top5_d4(t) < (double)max_sq_dist) {      // :128 / :198
+  if (is_edge) { const GridDesc gc = *gcp; knn5_grid(gc, map_c, cs_c, q, max_sq_dist, t); }
+  else { const GridDesc gs = *gsp; knn5_grid(gs, map_s, cs_s, q, max_sq_dist, t); }
+  if ((unsigned int)t.k4 != 0xffffffffu && (double)top5_d4(t) < (double)max_sq_dist) {      // :128 / :198
     // original map index -> position in the sorted map array (the fit kernel then gathers directly);
     // done here because this kernel runs at 8 waves/SIMD and hides the extra dependent load
     const int* po = is_edge ? pos_c : pos_s;
