@@ -115,7 +115,7 @@ struct msfl_handle_s {
   DevBuf dk[4];
   DevBuf ex[16];
   DevBuf od[16];
-  DevBuf vb[12];  // batched voxel filter
+  DevBuf vb[14];  // batched voxel filter
   DevBuf pp[5];   // per-point passes: pre-integration samples, staged points, dq, dp, flag
 
   PinRing pin;

@@ -597,7 +597,8 @@ __global__ void __launch_bounds__(256) voxel_batch_desc_kernel(VoxelBatchView v,
 // b = upper_bound(in_off, e) - 1 at position k = e - in_off[b]
 __global__ void __launch_bounds__(256) voxel_batch_key_kernel(VoxelBatchView v, const VoxelCloudDesc* __restrict__ desc,
                                                                const int* __restrict__ in_off, int n_valid, int cell_bits,
-                                                               unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+                                                               unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
+                                                               float4* __restrict__ pts_c) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_valid) return;
   const int b = find_scan_off(in_off, v.n_clouds, e);
@@ -609,7 +610,8 @@ __global__ void __launch_bounds__(256) voxel_batch_key_kernel(VoxelBatchView v, 
   const int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)d.min_b[2]);
   const unsigned long long cell = (unsigned long long)((long long)i0 + (long long)i1 * d.div_b[0] + (long long)i2 * d.div_b[0] * (long long)d.div_b[1]);
   keys[e] = ((unsigned long long)b << cell_bits) | (cell & ((1ull << cell_bits) - 1ull));
-  vals[e] = (unsigned)k;
+  vals[e] = (unsigned)e;
+  pts_c[e] = p;                 // the valid points, compacted: everything after the sort gathers from here
 }
 
 __global__ void __launch_bounds__(256) voxel_batch_flag_kernel(const unsigned long long* __restrict__ keys, int n, int* __restrict__ flag) {
@@ -618,28 +620,38 @@ __global__ void __launch_bounds__(256) voxel_batch_flag_kernel(const unsigned lo
   flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
 
-// one thread per voxel head: centroid of the run in arrival order; the head that opens a cloud also
-// publishes the output boundaries of every cloud since the previous non-empty one
-__global__ void __launch_bounds__(256) voxel_batch_centroid_kernel(VoxelBatchView v, const unsigned long long* __restrict__ keys,
-                                                                    const unsigned* __restrict__ vals, const int* __restrict__ flag,
-                                                                    const int* __restrict__ pos, int n, int cell_bits,
-                                                                    float4* __restrict__ out, int* __restrict__ out_off) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !flag[i]) return;
-  const unsigned long long key = keys[i];
-  const int b = (int)(key >> cell_bits);
+// after the sort: points into key order (independent one-level gathers, coalesced writes) + the list of run heads
+__global__ void __launch_bounds__(256) voxel_batch_gather_kernel(const float4* __restrict__ pts_c, const unsigned* __restrict__ vals,
+                                                                  const int* __restrict__ flag, const int* __restrict__ pos, int n,
+                                                                  float4* __restrict__ sp, int* __restrict__ head_pos) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  sp[j] = pts_c[vals[j]];
+  if (flag[j]) head_pos[pos[j] - 1] = j;
+}
+
+// one thread per voxel: centroid of its run (contiguous in `sp`) in arrival order, f32 accumulators; the
+// voxel that opens a cloud also publishes the output boundaries of every cloud since the previous non-empty one
+__global__ void __launch_bounds__(256) voxel_batch_centroid_kernel(const float4* __restrict__ sp, const unsigned long long* __restrict__ keys,
+                                                                    const int* __restrict__ head_pos, const int* __restrict__ pos, int n,
+                                                                    int n_clouds, int cell_bits, float4* __restrict__ out,
+                                                                    int* __restrict__ out_off) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = pos[n - 1];                                    // number of voxels in the batch
+  if (o >= m) return;
+  const int i = head_pos[o];
+  const int e = (o + 1 < m) ? head_pos[o + 1] : n;
   float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
-  int j = i;
-  for (; j < n && keys[j] == key; j++) {
-    const float4 p = vb_point(v, b, (int)vals[j]);
+  for (int j = i; j < e; j++) {
+    const float4 p = sp[j];
     sx += p.x; sy += p.y; sz += p.z; st += p.w;
   }
-  const float c = (float)(j - i);
-  const int o = pos[i] - 1;
+  const float c = (float)(e - i);
   out[o] = make_float4(sx / c, sy / c, sz / c, st / c);
+  const int b = (int)(keys[i] >> cell_bits);
   const int prev = i == 0 ? -1 : (int)(keys[i - 1] >> cell_bits);
   for (int cl = prev + 1; cl <= b; cl++) out_off[cl] = o;                 // empty clouds in between start (and end) here
-  if (j == n) { const int total = pos[n - 1]; for (int cl = b + 1; cl <= v.n_clouds; cl++) out_off[cl] = total; }
+  if (e == n) for (int cl = b + 1; cl <= n_clouds; cl++) out_off[cl] = m;
 }
 
 // exclusive scan of the per-cloud voxel counts (B is small: one workgroup, serial per 1024-chunk carry)
