@@ -605,18 +605,10 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   const bool use_cache = (pprime == nullptr);       // deskew keeps f64 points in global memory
   for (int i = threadIdx.x; i < ns; i += BLOCK) {
     d3 N, p; double d0;
-#ifdef MSFL_LM_FAKE_CACHE   /* timing experiment only: pretend every record is LDS-resident (wrong results) */
-    if (!FILL && use_cache) {
-      const int ii = i % kPlaneCache;
-      N = mk3(pc.nx[ii], pc.ny[ii], pc.nz[ii]); d0 = pc.d0[ii];
-      p = mk3((double)pc.px[ii], (double)pc.py[ii], (double)pc.pz[ii]);
-    } else {
-#else
     if (!FILL && use_cache && i < kPlaneCache) {
       N = mk3(pc.nx[i], pc.ny[i], pc.nz[i]); d0 = pc.d0[i];
       p = mk3((double)pc.px[i], (double)pc.py[i], (double)pc.pz[i]);
     } else {
-#endif
       const double* r4 = recp + 4 * (size_t)i;
       N = mk3(r4[0], r4[1], r4[2]); d0 = r4[3];
       if (pprime) { const size_t k = (size_t)(nc + i); p = mk3(pprime[3 * k], pprime[3 * k + 1], pprime[3 * k + 2]); }
