@@ -159,3 +159,47 @@ def test_deskew_variant_matches_oracle(gpu, oracle):
                                              np.zeros(3), np.zeros(3), guess)
         s, p1, _ = gpu.match_scan2map(corner, surf, guess)
         assert synth.pose_error(p0, p1)[0] < 1e-12
+
+
+def test_lattice_map_with_ties_and_duplicates(gpu, oracle):
+    """Exact-kNN stress: a lattice map (many exactly equal f32 distances), duplicated points, queries on
+    lattice nodes, on cell boundaries of the index and exactly on / just inside / just outside the
+    d^2 < 1.0 gate.  The total order (distance, index) must reproduce the oracle's selection, so the
+    fitted records agree."""
+    rng = np.random.default_rng(77)
+    g = np.arange(-6, 7, dtype=np.float32) * 0.5
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    plane = np.stack([X.ravel(), Y.ravel(), np.full(X.size, -1.5, np.float32)], 1)      # z = -1.5 lattice, 0.5 m pitch
+    wall = np.stack([np.full(X.size, 3.5, np.float32), X.ravel(), Y.ravel() + 1.5], 1)   # x = 3.5 lattice
+    origin_plane = np.stack([X.ravel() + 20.0, Y.ravel(), np.zeros(X.size, np.float32)], 1)   # z = 0: n.p = -1 has no solution
+    ms = np.concatenate([plane, wall, origin_plane, plane[::7]])                        # + exact duplicates
+    ms = np.concatenate([ms, np.zeros((len(ms), 1), np.float32)], 1).astype(np.float32)
+    ms = ms[rng.permutation(len(ms))]                                                   # index order != spatial order
+    line = np.stack([np.zeros(60, np.float32), np.zeros(60, np.float32), np.arange(60, dtype=np.float32) * 0.125], 1)
+    mc = np.concatenate([line, line[::5]])                                              # vertical pole with duplicates
+    mc = np.concatenate([mc, np.zeros((len(mc), 1), np.float32)], 1).astype(np.float32)
+    gpu.set_map(mc, ms)
+    q = [[0, 0, -1.5], [0.25, 0.25, -1.5], [0.5, 0, -1.5], [1.0, 1.0, -1.5], [2.999, 0, -1.5], [3.25, 0.25, 1.5], [0, 0, -0.54],
+         [0, 0, -0.5], [0, 0, -0.5001], [-3.0, -3.0, -1.5], [-3.5, 0, -1.5], [0.001, -0.001, -0.95], [3.5, 3.0, 4.5], [1.7, -2.2, -1.2],
+         [20.0, 0.25, 0.1], [2.6, 0.1, 0.3], [3.5, -2.75, 1.25]]
+    surf = np.array([p + [0.0] for p in q], np.float32)
+    corner = np.array([[0.1, 0.0, 1.0, 0], [0.0, 0.0, 3.3, 0], [0.99, 0.0, 2.0, 0], [1.0, 0.0, 2.0, 0], [0.0, 0.05, 7.4, 0],
+                       [0.0, 0.0, 8.4, 0]], np.float32)
+    for pose in (np.array([0, 0, 0, 0, 0, 0, 1.0]), np.array([0.125, -0.25, 0.0, 0, 0, 0, 1.0])):
+        rec = gpu.associate_scan2map(corner, surf, pose)
+        corr = oracle.associate_scan2map(mc, ms, corner, surf, pose)
+        ok_o = corr["kind"] != 0
+        assert np.array_equal(np.any(rec[:, 3:] != 0, axis=1), ok_o)
+        assert ok_o[len(corner):].sum() >= 8 and not ok_o[len(corner) + 14]      # the z = 0 lattice never yields a plane
+        nc = len(corner)
+        pl = ok_o.copy(); pl[:nc] = False
+        if pl.any():
+            assert np.max(np.abs(rec[pl, :3] - corr["C"][pl])) < 1e-9
+            assert np.max(np.abs(rec[pl, 3:] - corr["N"][pl])) < 1e-9
+        ed = ok_o.copy(); ed[nc:] = False
+        assert ed.sum() >= 3
+        n_dot = np.abs(np.sum(rec[ed, 3:] * corr["N"][ed], axis=1))            # eigenvector sign is free
+        assert np.all(np.abs(n_dot - 1) < 1e-9)
+        d = rec[ed, :3] - corr["C"][ed]
+        perp = d - np.sum(d * corr["N"][ed], axis=1, keepdims=True) * corr["N"][ed]
+        assert np.abs(perp).max() < 1e-9
