@@ -203,3 +203,53 @@ def test_lattice_map_with_ties_and_duplicates(gpu, oracle):
         d = rec[ed, :3] - corr["C"][ed]
         perp = d - np.sum(d * corr["N"][ed], axis=1, keepdims=True) * corr["N"][ed]
         assert np.abs(perp).max() < 1e-9
+
+
+def _synthetic_corr(rng, n_plane, n_edge, normals=None, noise=0.0, truth=None):
+    """Hand-made correspondences around a known pose: kind 1 = edge {p, C, N}, kind 2 = plane."""
+    from oracle.oracle import CORR
+    truth = truth if truth is not None else np.array([0.3, -0.2, 0.1, 0, 0, np.sin(0.05), np.cos(0.05)])
+    R = synth.quat_to_matrix(truth[3:])
+    corr = np.zeros(n_edge + n_plane, dtype=CORR)
+    for i in range(n_edge + n_plane):
+        p = rng.uniform(-20, 20, 3).astype(np.float32).astype(np.float64)            # features are f32 points
+        w = R @ p + truth[:3]
+        if normals is None:
+            N = rng.normal(size=3)
+        else:
+            N = np.array(normals[i % len(normals)], dtype=np.float64)
+        N /= np.linalg.norm(N)
+        corr[i]["p"], corr[i]["N"], corr[i]["kind"] = p, N, (1 if i < n_edge else 2)
+        corr[i]["C"] = w + noise * rng.normal(size=3) + (N * rng.normal() if i < n_edge else 0)   # an edge point slides along N
+    return corr, truth
+
+
+@pytest.mark.parametrize("case", ["generic", "at_optimum", "edges_only", "two_normals", "outliers"])
+def test_solver_corner_cases_follow_the_oracle(gpu, oracle, case):
+    """The trust-region logic outside the comfortable regime: already converged, only edges, a
+    rank-deficient geometry (two plane normals: the LM damping carries the solve), gross outliers
+    (Huber).  Same iteration / acceptance counts and the same pose as the oracle."""
+    rng = np.random.default_rng(5)
+    kw = dict(generic=dict(n_plane=400, n_edge=40, noise=0.01),
+              at_optimum=dict(n_plane=300, n_edge=30, noise=0.0),
+              edges_only=dict(n_plane=0, n_edge=120, noise=0.01),
+              two_normals=dict(n_plane=300, n_edge=0, noise=0.005, normals=[[0, 0, 1], [1, 0, 0]]),
+              outliers=dict(n_plane=400, n_edge=40, noise=0.01))[case]
+    corr, truth = _synthetic_corr(rng, **kw)
+    if case == "outliers":
+        corr["C"][::7] += rng.normal(scale=3.0, size=(len(corr[::7]), 3))
+    guess = truth.copy() if case == "at_optimum" else synth.perturb_pose(truth, rng, 0.2, 2.0)
+    ne = int((corr["kind"] == 1).sum())
+    corner = np.concatenate([corr["p"][:ne], np.zeros((ne, 1))], 1).astype(np.float32)
+    surf = np.concatenate([corr["p"][ne:], np.zeros((len(corr) - ne, 1))], 1).astype(np.float32)
+    rec = np.concatenate([corr["C"], corr["N"]], 1)
+    pose_o, summ = oracle.ceres_solve(corr, guess)
+    pose_g, info = gpu.solve_records(corner, surf, rec, guess)
+    assert info.lm_iterations[0] == summ.iterations and info.lm_successful[0] == summ.successful_steps, case
+    dt, dr = synth.pose_error(pose_g, pose_o)
+    assert dt < 1e-6 and dr < 1e-6, (case, dt, dr)
+    if case in ("generic", "edges_only", "outliers"):
+        et, er = synth.pose_error(pose_g, truth)
+        assert et < 0.05 and er < 0.01
+    if case == "at_optimum":
+        assert np.array_equal(pose_g, guess) or synth.pose_error(pose_g, guess)[0] < 1e-9
