@@ -250,6 +250,14 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
   const float gz0 = axis_gap(uz, cz - 1), gz1 = axis_gap(uz, cz), gz2 = axis_gap(uz, cz + 1);
   const float cellx = 1.0f / g.inv_cell_x;
   const float cellx2 = cellx * cellx;
+  // squared lower bounds of the kGridXSub cells left of / right of the query cell, outermost first: they
+  // are the same for all nine rows, so the per-row trimming is two adds and two compares per side
+  float gxa[kGridXSub], gxb[kGridXSub];
+#pragma unroll
+  for (int k = 0; k < kGridXSub; k++) {
+    const float ga = axis_gap(ux, xs + k), gb = axis_gap(ux, xe - k);
+    gxa[k] = ga * ga * cellx2; gxb[k] = gb * gb * cellx2;
+  }
   const msfl_f2 qxy = {q.x, q.y};
   // visit order of the 9 (dy,dz) rows: centre, 4 edge neighbours, 4 diagonal neighbours.
   // Fully unrolled: offsets are compile-time constants.
@@ -282,13 +290,16 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
     const float d4 = top5_d4(t);
     if (row2 > d4) continue;                  // d4 is the acceptance gate until five neighbours are known
     // trim the x range: drop end cells whose lower bound exceeds the 5th-best distance
+    // a cell is dropped when its lower bound exceeds d4; the bounds shrink towards the query, so count the
+    // leading run of dropped cells on each side
     int a = xs, b = xe;
+    bool da = true, db = true;
 #pragma unroll
     for (int k = 0; k < kGridXSub; k++) {
-      const float ga = axis_gap(ux, a), gb = axis_gap(ux, b);
-      if (a < b && row2 + ga * ga * cellx2 > d4) a++;
-      if (a < b && row2 + gb * gb * cellx2 > d4) b--;
+      da = da && (row2 + gxa[k] > d4); a += da ? 1 : 0;
+      db = db && (row2 + gxb[k] > d4); b -= db ? 1 : 0;
     }
+    if (a > b) continue;                      // only near the grid border: every remaining cell is out of reach
     scan(row, a, b);
   }
 }
@@ -354,6 +365,15 @@ struct BatchView {
 };
 
 // scan owning global record index g (upper bound - 1 over rec_off)
+__device__ __forceinline__ int find_scan(const int* __restrict__ rec_off, int n_scans, int g);
+// the same for a whole wavefront of consecutive g: the binary search runs once on the scalar unit for
+// the first lane's g, every lane then steps forward over the (rare) scan boundaries inside the wave
+__device__ __forceinline__ int find_scan_wave(const int* __restrict__ rec_off, int n_scans, int g) {
+  const int g0 = __builtin_amdgcn_readfirstlane(g);
+  int b = __builtin_amdgcn_readfirstlane(find_scan(rec_off, n_scans, g0));
+  while (b + 1 < n_scans && g >= rec_off[b + 1]) b++;
+  return b;
+}
 __device__ __forceinline__ int find_scan(const int* __restrict__ rec_off, int n_scans, int g) {
   int lo = 0, hi = n_scans;      // invariant: rec_off[lo] <= g < rec_off[hi]
   while (hi - lo > 1) {
@@ -388,7 +408,7 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
                      float max_sq_dist, DeskewView dv, int* __restrict__ nn) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bv.n_records) return;
-  const int b = find_scan(bv.rec_off, bv.n_scans, g);
+  const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);
   int* out = nn + 5 * (size_t)g;
   if (status[b] != 0) { out[0] = -1; return; }
   const int local = g - bv.rec_off[b];
@@ -445,7 +465,7 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bv.n_records) return;
   const int* in = nn + 5 * (size_t)g;
-  const int b = find_scan(bv.rec_off, bv.n_scans, g);
+  const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);
   const int local = g - bv.rec_off[b];
   const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
   const bool is_edge = local < nc;
@@ -482,7 +502,7 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
 __global__ void __launch_bounds__(256) pack_records_kernel(BatchView bv, const double* __restrict__ full, double* __restrict__ rec) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bv.n_records) return;
-  const int b = find_scan(bv.rec_off, bv.n_scans, g);
+  const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);
   const int local = g - bv.rec_off[b];
   const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
   const double* in = full + 6 * (size_t)g;
