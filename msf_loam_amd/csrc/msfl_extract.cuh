@@ -203,10 +203,18 @@ __device__ __forceinline__ int find_scan_off(const int* __restrict__ off, int n_
   return lo;
 }
 
+// consecutive g across a wavefront: one scalar binary search for the first lane, then a forward step
+__device__ __forceinline__ int find_scan_off_wave(const int* __restrict__ off, int n_scans, int g) {
+  const int g0 = __builtin_amdgcn_readfirstlane(g);
+  int b = __builtin_amdgcn_readfirstlane(find_scan_off(off, n_scans, g0));
+  while (b + 1 < n_scans && g >= off[b + 1]) b++;
+  return b;
+}
+
 __global__ void __launch_bounds__(256) extract_curvature_kernel(ExtractView v, ExtractParams prm) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= v.n_total) return;
-  const int b = find_scan_off(v.off, v.n_scans, g);
+  const int b = find_scan_off_wave(v.off, v.n_scans, g);
   const int o = v.off[b];
   const int i = g - o;
   const int N = v.n_full[b];
@@ -601,7 +609,7 @@ __global__ void __launch_bounds__(256) voxel_batch_key_kernel(VoxelBatchView v, 
                                                                float4* __restrict__ pts_c) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_valid) return;
-  const int b = find_scan_off(in_off, v.n_clouds, e);
+  const int b = find_scan_off_wave(in_off, v.n_clouds, e);
   const int k = e - in_off[b];
   const VoxelCloudDesc d = desc[b];
   const float4 p = vb_point(v, b, k);
