@@ -417,31 +417,17 @@ odom_bin_kernel(const float4* __restrict__ pts_all, const uint16_t* __restrict__
 }
 
 // L lanes (a power of two, one query per L-lane group) walk the (2r+1)^2 column square around
-// column (cx, cy): the 2 x rows run boundaries are fetched from the table one per lane, then every
-// row's run is read L targets at a time (coalesced); f(float4) per target.
+// column (cx, cy): every row's run is read L targets at a time (coalesced); f(float4) per target.
 template <int L, class F>
 __device__ __forceinline__ void odom_walk(const OdomIndex& ix, const unsigned* __restrict__ tab, const float4* __restrict__ sorted,
                                           int W, int H, int cx, int cy, int r, int sl, F&& f) {
   const int x0 = max(cx - r, 0), x1 = min(cx + r, W - 1);
   const int y0 = max(cy - r, 0), y1 = min(cy + r, H - 1);
   if (x0 > x1 || y0 > y1) return;
-  const int n_search = 2 * (y1 - y0 + 1);                  // <= 26
-  constexpr int kRounds = (2 * (2 * kOdomMaxLevel + 1) + L - 1) / L;
-  int res[kRounds];
-#pragma unroll
-  for (int k = 0; k < kRounds; k++) {
-    const int sidx = k * L + sl;
-    res[k] = 0;
-    if (sidx < n_search) res[k] = (int)tab[(y0 + (sidx >> 1)) * W + ((sidx & 1) ? x1 + 1 : x0)];   // row-major: the run ends where column x1 + 1 starts
-  }
-  for (int row = 0; row <= y1 - y0; row++) {
-    int b0 = 0, b1 = 0;
-#pragma unroll
-    for (int k = 0; k < kRounds; k++) {
-      const int v0 = __shfl(res[k], (2 * row) % L, L), v1 = __shfl(res[k], (2 * row + 1) % L, L);
-      if ((2 * row) / L == k) b0 = v0;
-      if ((2 * row + 1) / L == k) b1 = v1;
-    }
+  for (int y = y0; y <= y1; y++) {
+    // row-major table: the run of columns [x0, x1] ends where column x1 + 1 starts; the two loads are
+    // uniform inside the lane group (one transaction)
+    const int b0 = (int)tab[y * W + x0], b1 = (int)tab[y * W + x1 + 1];
     for (int i = b0 + sl; i < b1; i += L) f(sorted[i]);
   }
 }
@@ -453,21 +439,16 @@ __device__ __forceinline__ float odom_gap_sq(float3 q, float fx, float fy, int r
   return g * g * 0.9999f;
 }
 
+// minimum of a packed (distance bits << 32 | tie word) key over the L lanes of a query
 template <int L>
-__device__ __forceinline__ void group_min_lo(float& d, int& j) {      // min distance, ties -> smallest j
+__device__ __forceinline__ unsigned long long group_min_key(unsigned long long k) {
 #pragma unroll
   for (int o = L / 2; o > 0; o >>= 1) {
-    const float d2 = __shfl_xor(d, o); const int j2 = __shfl_xor(j, o);
-    if (d2 < d || (d2 == d && j2 < j)) { d = d2; j = j2; }
+    const unsigned lo = __shfl_xor((unsigned)k, o), hi = __shfl_xor((unsigned)(k >> 32), o);
+    const unsigned long long k2 = ((unsigned long long)hi << 32) | lo;
+    k = k2 < k ? k2 : k;
   }
-}
-template <int L>
-__device__ __forceinline__ void group_min_hi(float& d, int& j) {      // min distance, ties -> largest j (-1 = none)
-#pragma unroll
-  for (int o = L / 2; o > 0; o >>= 1) {
-    const float d2 = __shfl_xor(d, o); const int j2 = __shfl_xor(j, o);
-    if (d2 < d || (d2 == d && j2 > j)) { d = d2; j = j2; }
-  }
+  return k;
 }
 
 template <int L>
@@ -498,31 +479,30 @@ assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const
   const int cx = (int)fx - pd.ox, cy = (int)fy - pd.oy;           // may lie outside [0, W) x [0, H): the walk clips
   const unsigned* tab = ix.tab + (size_t)b * kOdomTabStride;
   const float4* sorted = ix.sorted + s0;
-  // ---- exact 1-NN (:169), ties -> lower index; w = ring << 24 | index, so (d, w & 0xffffff) orders candidates ----
-  float best = INFINITY; int bw = 0x7fffffff;
+  // Running minima are packed keys (f32 distance bits << 32 | tie word): distances are >= 0, so one
+  // unsigned compare realises (distance, tie) lexicographic order.
+  // ---- exact 1-NN (:169), ties -> lower index.  Tie word = ring << 24 | index: on a ring-monotone cloud
+  //      ordering by (ring, index) is ordering by index ----
+  unsigned long long kbest = ~0ull;
   for (int l = 0; l < 3; l++) {
     const int r = l == 0 ? 1 : l == 1 ? kOdomMidLevel : kOdomMaxLevel;
     odom_walk<L>(ix, tab, sorted, pd.W, pd.H, cx, cy, r, sl, [&](const float4 p) __attribute__((always_inline)) {
-      const float d = odom_dist(p, q);
-      const int w = __float_as_int(p.w);
-      if (d < best || (d == best && (w & 0xffffff) < (bw & 0xffffff))) { best = d; bw = w; }
+      const unsigned long long k = ((unsigned long long)__float_as_uint(odom_dist(p, q)) << 32) | (unsigned)__float_as_int(p.w);
+      kbest = k < kbest ? k : kbest;
     });
-#pragma unroll
-    for (int o = L / 2; o > 0; o >>= 1) {
-      const float d2 = __shfl_xor(best, o); const int w2 = __shfl_xor(bw, o);
-      if (d2 < best || (d2 == best && (w2 & 0xffffff) < (bw & 0xffffff))) { best = d2; bw = w2; }
-    }
-    if (best < odom_gap_sq(q, fx, fy, r)) break;
+    kbest = group_min_key<L>(kbest);
+    if (__uint_as_float((unsigned)(kbest >> 32)) < odom_gap_sq(q, fx, fy, r)) break;
   }
-  if (!(best < thr)) { if (sl < 4) out[sl] = 0.0; return; }       // :173
-  const int closest = bw & 0xffffff, id = (int)((unsigned)bw >> 24);
-  // ---- ring-window minima (:183-232) ----
+  if (!(__uint_as_float((unsigned)(kbest >> 32)) < thr)) { if (sl < 4) out[sl] = 0.0; return; }       // :173 (NaN / none: not <)
+  const int closest = (int)((unsigned)kbest & 0xffffffu), id = (int)((unsigned)kbest >> 24 & 0xffu);
+  // ---- ring-window minima (:183-232): forward ties -> lowest index, backward ties -> highest index
+  //      (tie word 0xffffff - index); tie word 0xffffffff = nothing found ----
   const float hi_ring = (float)id + (float)ov.nearby_scan, lo_ring = (float)id - (float)ov.nearby_scan;
-  float f2, f3, b2, b3;
-  int jf2, jf3, jb2, jb3;
+  const unsigned long long none = ((unsigned long long)__float_as_uint(thr) << 32) | 0xffffffffull;
+  unsigned long long kf2, kf3, kb2, kb3;
   for (int l = 0; l < 3; l++) {
     const int r = l == 0 ? 1 : l == 1 ? kOdomMidLevel : kOdomMaxLevel;
-    f2 = f3 = b2 = b3 = thr; jf2 = jf3 = 0x7fffffff; jb2 = jb3 = -1;      // each level re-walks the inner square too
+    kf2 = kf3 = kb2 = kb3 = none;                                   // each level re-walks the inner square too
     odom_walk<L>(ix, tab, sorted, pd.W, pd.H, cx, cy, r, sl, [&](const float4 p) __attribute__((always_inline)) {
       const int w = __float_as_int(p.w), j = w & 0xffffff, rj = (int)((unsigned)w >> 24);
       if (j == closest || (float)rj > hi_ring || (float)rj < lo_ring) return;
@@ -530,22 +510,23 @@ assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const
       if (!(d < thr)) return;                                    // every running minimum starts at the 25 m^2 gate
       // branch-free updates (selects): branches here make the compiler address the minima through memory
       const bool fwd = j > closest, same = fwd ? rj <= id : rj >= id;
-      const bool u_f2 = fwd && same && (d < f2 || (d == f2 && j < jf2));
-      const bool u_f3 = fwd && !same && (d < f3 || (d == f3 && j < jf3));
-      const bool u_b2 = !fwd && same && (d < b2 || (d == b2 && j > jb2));
-      const bool u_b3 = !fwd && !same && (d < b3 || (d == b3 && j > jb3));
-      f2 = u_f2 ? d : f2; jf2 = u_f2 ? j : jf2;
-      f3 = u_f3 ? d : f3; jf3 = u_f3 ? j : jf3;
-      b2 = u_b2 ? d : b2; jb2 = u_b2 ? j : jb2;
-      b3 = u_b3 ? d : b3; jb3 = u_b3 ? j : jb3;
+      const unsigned long long kd = (unsigned long long)__float_as_uint(d) << 32;
+      const unsigned long long kf = kd | (unsigned)j, kb = kd | (unsigned)(0xffffff - j);
+      kf2 = (fwd && same && kf < kf2) ? kf : kf2;
+      kf3 = (fwd && !same && kf < kf3) ? kf : kf3;
+      kb2 = (!fwd && same && kb < kb2) ? kb : kb2;
+      kb3 = (!fwd && !same && kb < kb3) ? kb : kb3;
     });
-    group_min_lo<L>(f2, jf2); group_min_lo<L>(f3, jf3); group_min_hi<L>(b2, jb2); group_min_hi<L>(b3, jb3);
+    kf2 = group_min_key<L>(kf2); kf3 = group_min_key<L>(kf3); kb2 = group_min_key<L>(kb2); kb3 = group_min_key<L>(kb3);
     const float g = odom_gap_sq(q, fx, fy, r);
-    if (fminf(f2, b2) < g && fminf(f3, b3) < g) break;
+    const float m2 = __uint_as_float((unsigned)((kf2 < kb2 ? kf2 : kb2) >> 32)), m3 = __uint_as_float((unsigned)((kf3 < kb3 ? kf3 : kb3) >> 32));
+    if (m2 < g && m3 < g) break;
   }
   if (sl != 0) return;
-  if (jf2 == 0x7fffffff) jf2 = -1;
-  if (jf3 == 0x7fffffff) jf3 = -1;
+  const float f2 = __uint_as_float((unsigned)(kf2 >> 32)), f3 = __uint_as_float((unsigned)(kf3 >> 32));
+  const float b2 = __uint_as_float((unsigned)(kb2 >> 32)), b3 = __uint_as_float((unsigned)(kb3 >> 32));
+  const int jf2 = (unsigned)kf2 == 0xffffffffu ? -1 : (int)(unsigned)kf2, jf3 = (unsigned)kf3 == 0xffffffffu ? -1 : (int)(unsigned)kf3;
+  const int jb2 = (unsigned)kb2 == 0xffffffffu ? -1 : 0xffffff - (int)(unsigned)kb2, jb3 = (unsigned)kb3 == 0xffffffffu ? -1 : 0xffffff - (int)(unsigned)kb3;
   const int min2 = (jb2 >= 0 && b2 < f2) ? jb2 : jf2;           // backward continues the forward minimum with strict '<'
   const int min3 = (jb3 >= 0 && b3 < f3) ? jb3 : jf3;
   d3 C = mk3(0, 0, 0), N = mk3(0, 0, 0);
