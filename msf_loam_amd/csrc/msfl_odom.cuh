@@ -31,8 +31,12 @@ constexpr int kOdomTile = 1024;
 
 __device__ __forceinline__ float odom_dist(float4 a, float3 q) {
   // (ax-qx)*(ax-qx) + (ay-qy)*(ay-qy) + (az-qz)*(az-qz) in f32 (:102-108); same order as L2_Simple
-  const float dx = a.x - q.x, dy = a.y - q.y, dz = a.z - q.z;
-  return dx * dx + dy * dy + dz * dz;
+  // x and y as one packed-f32 pair (two individually rounded IEEE operations per instruction): same bits
+  const msfl_f2 axy = {a.x, a.y}, qxy = {q.x, q.y};
+  const msfl_f2 dxy = axy - qxy;
+  const msfl_f2 sxy = dxy * dxy;
+  const float dz = a.z - q.z;
+  return sxy.x + sxy.y + dz * dz;
 }
 
 // bv.corner = curr sharp, bv.surf = curr flat; records in feature order (sharp first).
