@@ -578,20 +578,31 @@ __device__ __forceinline__ void huber_rho(double a, double s, double& rho0, doub
 #ifndef MSFL_LM_BLOCK
 #define MSFL_LM_BLOCK 256
 #endif
-constexpr int kLmBlock = MSFL_LM_BLOCK;                        // threads per scan in the LM solve
+constexpr int kLmBlock = MSFL_LM_BLOCK;                        // threads per scan in the scan-to-map LM solve
+#ifndef MSFL_ODOM_LM_BLOCK
+#define MSFL_ODOM_LM_BLOCK 128
+#endif
+constexpr int kOdomLmBlock = MSFL_ODOM_LM_BLOCK;               // scan-to-scan: ~500 records per pair
 #ifndef MSFL_LM_EDGE_CACHE
 #define MSFL_LM_EDGE_CACHE 0
 #endif
 // Optional LDS cache for the edge records (build switch, default off): the edge loop has only 2-3
 // iterations per lane and takes 26 % of the evaluation time for 11 % of the records, but caching them
 // (at the planes' expense) measured 0.336 / 0.338 ms vs 0.331 ms without.
-constexpr int kEdgeCache = kLmBlock == 256 ? MSFL_LM_EDGE_CACHE : 0;                    // 60 B each
-constexpr int kPlaneCache = kLmBlock == 256 ? (1728 - (kEdgeCache * 60 + 43) / 44) & ~63 : 832;   // 76 KB x 2 workgroups per CU, or 36.6 KB x 4
+// cache sizes per workgroup size: 76 KB x 2 workgroups per CU (256 threads), 36.6 KB x 4 (128: the small
+// scan-to-scan problems, measured 0.365 ms per call vs 0.448 with 256 threads and 0.382 with 64), 17 KB x 8 (64:
+// the small scan-to-scan problems, one wavefront per pair, no cross-wave barrier)
+constexpr int lm_edge_cache(int block) { return block == 256 ? MSFL_LM_EDGE_CACHE : 0; }      // 60 B each
+constexpr int lm_plane_cache(int block) {
+  return block == 256 ? ((1728 - (lm_edge_cache(256) * 60 + 43) / 44) & ~63) : block == 128 ? 832 : 384;
+}
+template <int BLOCK>
 struct PlaneCache {
-  double nx[kPlaneCache], ny[kPlaneCache], nz[kPlaneCache], d0[kPlaneCache];
-  float px[kPlaneCache], py[kPlaneCache], pz[kPlaneCache];
-  double ecx[kEdgeCache + 1], ecy[kEdgeCache + 1], ecz[kEdgeCache + 1], enx[kEdgeCache + 1], eny[kEdgeCache + 1], enz[kEdgeCache + 1];
-  float epx[kEdgeCache + 1], epy[kEdgeCache + 1], epz[kEdgeCache + 1];
+  static constexpr int kPlanes = lm_plane_cache(BLOCK), kEdges = lm_edge_cache(BLOCK);
+  double nx[kPlanes], ny[kPlanes], nz[kPlanes], d0[kPlanes];
+  float px[kPlanes], py[kPlanes], pz[kPlanes];
+  double ecx[kEdges + 1], ecy[kEdges + 1], ecz[kEdges + 1], enx[kEdges + 1], eny[kEdges + 1], enz[kEdges + 1];
+  float epx[kEdges + 1], epy[kEdges + 1], epz[kEdges + 1];
 };
 
 // FILL: first pass of a solve (records come from global memory and are copied into the cache);
@@ -614,7 +625,7 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
                                               const float4* __restrict__ surf, int ns,
                                               const double* __restrict__ pprime,   // may be null
                                               const double* __restrict__ rec,      // this scan's records
-                                              PlaneCache& pc,
+                                              PlaneCache<BLOCK>& pc,
                                               double (&acc)[kAcc], int& n_edge, int& n_plane) {
 #pragma unroll
   for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
@@ -624,7 +635,7 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   // edges: {C, N}, r = N x (R p + t - C)                                       lidar_factor.cc:12
   for (int i = threadIdx.x; i < nc; i += BLOCK) {
     d3 C, N, p;
-    if (!FILL && pprime == nullptr && i < kEdgeCache) {
+    if (!FILL && pprime == nullptr && i < PlaneCache<BLOCK>::kEdges) {
       C = mk3(pc.ecx[i], pc.ecy[i], pc.ecz[i]); N = mk3(pc.enx[i], pc.eny[i], pc.enz[i]);
       p = mk3((double)pc.epx[i], (double)pc.epy[i], (double)pc.epz[i]);
     } else {
@@ -635,7 +646,7 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
       else {
         const float4 f = corner[i];                              // curr_point: untransformed (:146)
         p = mk3((double)f.x, (double)f.y, (double)f.z);
-        if (FILL && i < kEdgeCache) {
+        if (FILL && i < PlaneCache<BLOCK>::kEdges) {
           pc.ecx[i] = C.x; pc.ecy[i] = C.y; pc.ecz[i] = C.z; pc.enx[i] = N.x; pc.eny[i] = N.y; pc.enz[i] = N.z;
           pc.epx[i] = f.x; pc.epy[i] = f.y; pc.epz[i] = f.z;
         }
@@ -659,7 +670,7 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   const bool use_cache = (pprime == nullptr);       // deskew keeps f64 points in global memory
   for (int i = threadIdx.x; i < ns; i += BLOCK) {
     d3 N, p; double d0;
-    if (!FILL && use_cache && i < kPlaneCache) {
+    if (!FILL && use_cache && i < PlaneCache<BLOCK>::kPlanes) {
       N = mk3(pc.nx[i], pc.ny[i], pc.nz[i]); d0 = pc.d0[i];
       p = mk3((double)pc.px[i], (double)pc.py[i], (double)pc.pz[i]);
     } else {
@@ -669,7 +680,7 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
       else {
         const float4 f = surf[i];                              // curr_point: untransformed (:221)
         p = mk3((double)f.x, (double)f.y, (double)f.z);
-        if (FILL && i < kPlaneCache) {
+        if (FILL && i < PlaneCache<BLOCK>::kPlanes) {
           pc.nx[i] = N.x; pc.ny[i] = N.y; pc.nz[i] = N.z; pc.d0[i] = d0;
           pc.px[i] = f.x; pc.py[i] = f.y; pc.pz[i] = f.z;
         }
@@ -941,7 +952,7 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
                 double* __restrict__ poses, int* __restrict__ status, DevMatchInfo* __restrict__ info,
                 int outer_it, SolverParams prm) {
   __shared__ LmShared<BLOCK> sh;
-  __shared__ PlaneCache s_cache;
+  __shared__ PlaneCache<BLOCK> s_cache;
   const int b = blockIdx.x;
   if (status[b] != 0) return;
   const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
