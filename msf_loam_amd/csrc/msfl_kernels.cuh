@@ -591,7 +591,7 @@ constexpr int kOdomLmBlock = MSFL_ODOM_LM_BLOCK;               // scan-to-scan: 
 // (at the planes' expense) measured 0.336 / 0.338 ms vs 0.331 ms without.
 // cache sizes per workgroup size: 76 KB x 2 workgroups per CU (256 threads), 36.6 KB x 4 (128: the small
 // scan-to-scan problems, measured 0.365 ms per call vs 0.448 with 256 threads and 0.382 with 64), 17 KB x 8 (64:
-// the small scan-to-scan problems, one wavefront per pair, no cross-wave barrier)
+// one wavefront per problem, no cross-wave barrier)
 constexpr int lm_edge_cache(int block) { return block == 256 ? MSFL_LM_EDGE_CACHE : 0; }      // 60 B each
 constexpr int lm_plane_cache(int block) {
   return block == 256 ? ((1728 - (lm_edge_cache(256) * 60 + 43) / 44) & ~63) : block == 128 ? 832 : 384;
