@@ -132,3 +132,37 @@ def test_batched_voxel_filter_matches_oracle_per_cloud(gpu, oracle):
     for b, f in enumerate(feats):
         assert np.array_equal(out[out_off[b]:out_off[b + 1]], oracle.voxel_grid(f["full"][f["less_flat"]], 0.4)), b
     assert np.array_equal(out[out_off[1]:out_off[2]], gpu.voxel_downsample(feats[1]["full"][feats[1]["less_flat"]], 0.4))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_odd_scans_bit_exact(gpu, oracle, seed):
+    """Differential fuzzing on shapes a driver rarely produces: 1-5 rings out of 128, rings shorter than
+    the 11-point curvature margin, interleaved / grouped ring order, duplicated points, NaN / inf / too-near
+    points, quantised coordinates (curvature ties), a full turn that wraps the relative time."""
+    rng = np.random.default_rng(1000 + seed)
+    n_rings = int(rng.integers(1, 6))
+    ring_ids = np.sort(rng.choice(128, n_rings, replace=False))
+    n = int(rng.integers(40, 4000))
+    ring = ring_ids[rng.integers(0, n_rings, n)].astype(np.uint16)
+    if seed % 3 == 0:
+        ring = np.sort(ring)                                          # grouped by ring instead of interleaved
+    if seed % 4 == 1 and n_rings > 1:
+        ring[ring == ring_ids[0]] = ring_ids[1]
+        ring[: int(rng.integers(1, 10))] = ring_ids[0]                # a ring with fewer than 11 points
+    az = np.sort(rng.uniform(-np.pi, np.pi, n))[::-1] if seed % 2 == 0 else np.cumsum(rng.uniform(0, 4 * np.pi / n, n)) % (2 * np.pi) - np.pi
+    rad = rng.uniform(0.2, 40.0, n)
+    if seed % 5 == 2:
+        rad = np.round(rad, 0)                                         # lattice radii: many equal curvatures
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, 0], pts[:, 1] = rad * np.cos(az), rad * np.sin(az)
+    pts[:, 2] = rng.normal(0, 0.5, n) if seed % 2 else np.round(rng.normal(0, 0.5, n), 1)
+    k = max(1, n // 50)
+    idx = rng.choice(n, 4 * k, replace=False)
+    pts[idx[:k], 0] = np.nan
+    pts[idx[k:2 * k], 1] = np.inf
+    pts[idx[2 * k:3 * k], :3] *= 0.001                                # inside min_range
+    dup = idx[3 * k:]
+    pts[dup] = pts[(dup + 1) % n]                                     # exact duplicates of a neighbour
+    fo = oracle.extract_features(pts, ring)
+    f = gpu.extract_features(pts, ring, allow=(capi.BAD_ARG,))
+    _check(f, fo)
