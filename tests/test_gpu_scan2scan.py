@@ -192,3 +192,38 @@ def test_empty_and_nonfinite_clouds(gpu, oracle):
         assert s == status[b] == 0 and np.array_equal(p, poses[b]), b
         assert np.all(np.isfinite(p))
     assert info[2].n_plane[0] in (info[0].n_plane[0], info[0].n_plane[0] - 1)         # the NaN query drops out, nothing else
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_pairs_three_paths_agree(gpu, oracle, seed):
+    """Differential fuzzing of stage B: previous-scan clouds thinned per ring, rings removed, a block of the
+    cloud moved out of order, large initial offsets.  Single-pair call (wave kernel), 45-pair batch (tiled
+    edges + column-grid planes or the brute-force fallback) and the oracle must agree."""
+    rng = np.random.default_rng(4000 + seed)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    base = list(_clouds(*_pair(oracle, seed % 4)))
+    c = [np.copy(a) for a in base]
+    for k in (0, 2):                                              # thin the previous scan's clouds
+        keep = rng.uniform(size=len(c[k])) < rng.uniform(0.2, 1.0)
+        drop_ring = rng.integers(0, 16)
+        keep &= c[k + 1] != drop_ring
+        c[k], c[k + 1] = c[k][keep], c[k + 1][keep]
+    if seed % 2:                                                  # a block out of ring order -> brute-force planes
+        n = len(c[2]); a, b = sorted(rng.integers(0, n, 2))
+        order = np.concatenate([np.arange(a, b), np.arange(0, a), np.arange(b, n)])
+        c[2], c[3] = c[2][order], c[3][order]
+    sel = rng.uniform(size=len(c[5])) < rng.uniform(0.3, 1.0)
+    c[5] = c[5][sel]
+    guess = ident.copy()
+    guess[:3] = rng.normal(0, [0.5, 0.5, 0.05])
+    yaw = rng.normal(0, 0.02)
+    guess[5], guess[6] = np.sin(yaw / 2), np.cos(yaw / 2)
+    rc, pose_o, info_o = oracle.match_scan2scan(*c, guess)
+    s, pose_g, info_g = gpu.match_scan2scan(*c, guess)
+    assert s == rc
+    assert list(info_g.n_edge) == list(info_o.n_edge) and list(info_g.n_plane) == list(info_o.n_plane)
+    assert max(synth.pose_error(pose_g, pose_o)) < TIGHT
+    pairs = [c] * 45
+    guesses = np.stack([guess] * 45)
+    poses, status, _ = gpu.match_scan2scan_batch(_batch_sets(pairs), guesses)
+    assert np.all(status == s) and all(np.array_equal(poses[b], pose_g) for b in (0, 17, 44))
