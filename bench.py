@@ -104,8 +104,8 @@ def cpu_baseline(inp, sample, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scans", type=int, default=1024, help="scans per GPU per step (BASELINE configs[1]: 1024)")
     ap.add_argument("--map-points", type=int, default=200000)
     ap.add_argument("--cpu-sample", type=int, default=128, help="scans timed on the CPU oracle (0 disables)")
