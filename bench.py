@@ -7,7 +7,7 @@ association + line/plane fit -> Ceres-semantics LM(<=6)+Huber(0.1)]), inputs alr
 HBM.  With N > 1 every rank registers its own B scans (weak scaling) against a replicated map and
 the poses are gathered with one RCCL all_gather per step.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
