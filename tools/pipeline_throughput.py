@@ -2,7 +2,9 @@
 surf 0.4 m) -> scan-to-map registration, B scans per call, nothing but offsets and counts visiting
 the host.  Reports per-stage and end-to-end throughput and checks the poses against ground truth
 and against the host-memory single-scan path.  Run on the GPU box:
-    python tools/pipeline_throughput.py [B] [steps]"""
+    python tools/pipeline_throughput.py [B] [steps] [beams: 16|64] [map_points]
+BASELINE.json shapes per GPU: configs[1] = 1024 16 200000; configs[3] (10k x 64-beam over 8 GPUs) = 1250 3 64 200000;
+configs[4] (5k scans vs a 2M-point map over 8 GPUs) = 625 5 16 2000000."""
 import ctypes as C
 import json
 import os
@@ -17,13 +19,16 @@ from msf_loam_amd import capi, synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+BEAMS = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+MAP_POINTS = int(sys.argv[4]) if len(sys.argv) > 4 else 200000
+SCAN_KW = dict(n_beams=64, n_az=1900, elev=(-24.8, 2.0)) if BEAMS == 64 else {}
 dev = torch.device("cuda", 0)
-world = synth.World(ground_half=synth.ground_half_for_target(200000))
+world = synth.World(ground_half=synth.ground_half_for_target(MAP_POINTS))
 map_c, map_s = synth.make_map(world)
 truth = synth.random_poses(B, synth.SEED + 900)
 rng = np.random.default_rng(9)
 guess = np.stack([synth.perturb_pose(p, rng, 0.3, 3.0) for p in truth])
-scans = [synth.make_scan(world, truth[i], synth.SEED + 901 + i) for i in range(B)]
+scans = [synth.make_scan(world, truth[i], synth.SEED + 901 + i, **SCAN_KW) for i in range(B)]
 pts = np.concatenate([p for p, _ in scans])
 ring = np.concatenate([r for _, r in scans])
 off = np.cumsum([0] + [len(p) for p, _ in scans]).astype(np.int32)
@@ -117,7 +122,7 @@ for i in (0, B // 2, B - 1):
     s = h2.voxel_downsample(fe["full"][fe["less_flat"]], 0.4)
     _, p, _ = h2.match_scan2map(c, s, guess[i])
     same = same and np.array_equal(p, poses[i])
-print(json.dumps({"pipeline": {"scans": B, "points": int(n), "features_after_voxel": int(corner_off[-1] + surf_off[-1]),
+print(json.dumps({"pipeline": {"scans": B, "beams": BEAMS, "map_points": int(len(map_c) + len(map_s)), "points": int(n), "features_after_voxel": int(corner_off[-1] + surf_off[-1]),
                                "ms_extract": 1e3 * t_ext, "ms_extract_again": 1e3 * t_ext2, "ms_voxel": 1e3 * t_vox, "ms_register(incl. map index)": 1e3 * t_reg,
                                "ms_end_to_end": 1e3 * t_all, "scans_per_s_end_to_end": B / t_all,
                                "max_pose_error_vs_truth": [err_t, err_r], "equals_host_single_scan_path": bool(same),
