@@ -162,9 +162,15 @@ def main():
         h.set_map(d_map_c, d_map_s, n_mc, n_ms, capi.MEM_DEVICE)      # kd-tree build equivalent, per batch
         h.match_scan2map_batch_device(B, d_corner, co, d_surf, so, d_poses, d_status)
         if gather is not None:
-            gather.all_gather(d_poses, d_status)                     # RCCL pose gather
+            if os.environ.get("MSFL_GATHER_ASYNC") == "1":
+                gather.all_gather_async(d_poses, d_status)           # on a side stream, under the next step's compute
+            else:
+                gather.all_gather(d_poses, d_status)                 # RCCL pose gather on the compute stream (measured
+                                                                     # faster at N=1: 1.844 vs 1.864 ms/step)
 
     def barrier():
+        if gather is not None:
+            gather.wait()
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()

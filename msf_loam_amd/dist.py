@@ -56,6 +56,44 @@ class PoseGather:
             dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))
         return self.recv[:, :, :7], self.recv[:, :, 7]      # status as f64 view; cast when consumed
 
+    # --- pipelined form: the collective of batch k runs on a side stream under the compute of batch k+1 ---
+    def all_gather_async(self, poses, status):
+        """Pack on the current stream, gather on a side stream.  Results are valid after wait().  Two send /
+        receive buffers alternate, so the caller may overwrite `poses` right away and the previous result
+        stays readable until the call after next."""
+        if self.send.device.type != "cuda":
+            return self.all_gather(poses, status)
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream(device=self.send.device)
+            self._bufs = [(self.send, self.recv), (torch.empty_like(self.send), torch.empty_like(self.recv))]
+            self._done = [None, None]
+            self._k = 0
+        k = self._k
+        self._k ^= 1
+        send, recv = self._bufs[k]
+        cur = torch.cuda.current_stream(self.send.device)
+        if self._done[k] is not None:
+            cur.wait_event(self._done[k])                     # the collective that last read this send buffer
+        send[:, :7].copy_(poses.reshape(self.B, 7))
+        send[:, 7].copy_(status.reshape(self.B))
+        packed = torch.cuda.Event()
+        packed.record(cur)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(packed)
+            if not dist.is_initialized():
+                recv[0].copy_(send)
+            else:
+                dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+            self._done[k] = torch.cuda.Event()
+            self._done[k].record(self._side)
+        self._last = recv
+        return recv[:, :, :7], recv[:, :, 7]
+
+    def wait(self):
+        """Join the side stream: everything gathered so far is visible to the current stream afterwards."""
+        if hasattr(self, "_side"):
+            torch.cuda.current_stream(self.send.device).wait_stream(self._side)
+
 
 def gather_ragged(poses, status, n_total):
     """Gather block-partitioned results of uneven shards back into scan order on every rank."""
