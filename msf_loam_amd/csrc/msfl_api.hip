@@ -433,7 +433,7 @@ void msfl_destroy(msfl_handle* h) {
     (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(msfl::g_lm_prof), sizeof(v));
     if (v[5]) fprintf(stderr, "[lm profile] per solve (100 MHz ticks): eval %.0f reduce %.0f serial %.0f total %.0f passes %.2f solves %llu\n",
                       (double)v[0] / v[5], (double)v[1] / v[5], (double)v[2] / v[5], (double)v[3] / v[5], (double)v[4] / v[5], v[5]);
-    if (v[5]) fprintf(stderr, "[lm profile] inside eval: edge loop %.0f plane loop %.0f ticks per solve\n", (double)v[6] / v[5], (double)v[7] / v[5]);
+    if (v[5]) fprintf(stderr, "[lm profile] lane-0 logic: tr_decide %.0f tr_propose %.0f ticks per solve\n", (double)v[6] / v[5], (double)v[7] / v[5]);
   }
 #endif
   (void)hipSetDevice(h->device);

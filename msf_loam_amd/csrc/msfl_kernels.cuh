@@ -694,7 +694,6 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
     acc_row(acc, R, p, N, r, sqrt(rho1));                      // :38-39
   }
   LM_T(t_planes_done);
-  LM_ADD(6, t_edges_done - t_eval_begin); LM_ADD(7, t_planes_done - t_edges_done);
 }
 
 // Trust-region state of one solve.  Lives in LDS so that the evaluation passes (which every lane
@@ -1022,7 +1021,18 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
     LM_T(t1);
     block_reduce<BLOCK>(sh, acc, ne, np);
     LM_T(t2);
+#ifdef MSFL_LM_PROFILE
+    if (threadIdx.x == 0) {
+      const unsigned long long c0 = wall_clock64();
+      const int cont = tr_decide(tr, sh.red, prm);
+      const unsigned long long c1 = wall_clock64();
+      sh.go = cont ? tr_propose(tr, prm) : 0;
+      const unsigned long long c2 = wall_clock64();
+      atomicAdd(&g_lm_prof[6], c1 - c0); atomicAdd(&g_lm_prof[7], c2 - c1);
+    }
+#else
     if (threadIdx.x == 0) sh.go = tr_decide(tr, sh.red, prm) ? tr_propose(tr, prm) : 0;
+#endif
     __syncthreads();
     LM_T(t3);
     LM_ADD(0, t1 - t0); LM_ADD(1, t2 - t1); LM_ADD(2, t3 - t2); LM_ADD(4, 1);
