@@ -55,6 +55,19 @@ __device__ __forceinline__ bool point_valid(float4 p, double min_range) {
   return !((double)nrm < min_range || !isfinite(p.x) || !isfinite(p.y) || !isfinite(p.z));
 }
 
+// lanes of the wave that are valid and carry the same ring id (< 128): seven ballots, one per ring bit,
+// instead of one loop iteration per distinct ring in the group (a 64-beam driver interleaves all rings)
+__device__ __forceinline__ unsigned long long same_ring_lanes(bool valid, int r) {
+  unsigned long long m = __ballot(valid);
+#pragma unroll
+  for (int bit = 0; bit < 7; bit++) {
+    const bool set = (r >> bit) & 1;
+    const unsigned long long b = __ballot(valid && set);
+    m &= set ? b : ~b;
+  }
+  return m;
+}
+
 // Each of the 16 wavefronts owns a CONTIGUOUS slice of the driver-order cloud, so the stable ring
 // split needs no per-chunk workgroup barriers: pass A counts (wave, ring) populations, one scan
 // turns them into write cursors, pass B re-walks the slice and scatters with wave-local ranks
@@ -85,15 +98,10 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
       valid = point_valid(in[i], prm.min_range);
       if (valid) { r = in_ring[i]; if (r >= kMaxRings) { bad = 1; valid = false; } }   // CHECK_LT(point.ring, 128), :136
     }
-    unsigned long long remaining = __ballot(valid);
-    if (remaining && first == 0x7fffffff) first = g + (__ffsll((long long)remaining) - 1);
-    while (remaining) {
-      const int leader = __ffsll((long long)remaining) - 1;
-      const int lead_ring = __shfl(r, leader);
-      const unsigned long long m = __ballot(valid && r == lead_ring);
-      if (lane == leader) s_cur[wave][lead_ring] += __popcll(m);
-      remaining &= ~m;
-    }
+    const unsigned long long any_valid = __ballot(valid);
+    if (any_valid && first == 0x7fffffff) first = g + (__ffsll((long long)any_valid) - 1);
+    const unsigned long long m = same_ring_lanes(valid, r);
+    if (valid && lane == __ffsll((long long)m) - 1) s_cur[wave][r] += __popcll(m);     // one leader per distinct ring
   }
   bad = __any(bad) ? 1 : 0;
   if (lane == 0) { s_first[wave] = first; s_badw[wave] = bad; }
@@ -153,15 +161,11 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
       if (valid) r = in_ring[i];
     }
     int dst = 0;
-    unsigned long long remaining = __ballot(valid);
-    while (remaining) {
-      const int leader = __ffsll((long long)remaining) - 1;
-      const int lead_ring = __shfl(r, leader);
-      const unsigned long long m = __ballot(valid && r == lead_ring);
-      const int cur = s_cur[wave][lead_ring];                // uniform read, before the leader advances it
-      if (valid && r == lead_ring) dst = cur + __popcll(m & ((1ull << lane) - 1ull));
-      if (lane == leader) s_cur[wave][lead_ring] = cur + __popcll(m);
-      remaining &= ~m;
+    const unsigned long long m = same_ring_lanes(valid, r);
+    if (valid) {
+      const int cur = s_cur[wave][r];                        // every lane of a ring reads the cursor ...
+      dst = cur + __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == __ffsll((long long)m) - 1) s_cur[wave][r] = cur + __popcll(m);   // ... before its leader advances it
     }
     if (valid) {
       const double ori = -atan2((double)p.y, (double)p.x);                 // :139
