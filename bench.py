@@ -249,7 +249,8 @@ def main():
             "prep_s": t_prep,
             "n_failed": int((status_gpu != 0).sum()),
         }
-        if args.cpu_sample > 0:
+        out["cpu_baseline"] = None                 # timed on rank 0 at N=1 only (the other ranks would idle behind it)
+        if args.cpu_sample > 0 and world_size == 1:
             cores = os.cpu_count() or 1
             cb = cpu_baseline(inp, args.cpu_sample, cores)
             dts, drs = zip(*[synth.pose_error(poses_gpu[i], cb["poses"][i]) for i in range(cb["n"])])
