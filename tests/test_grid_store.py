@@ -126,3 +126,35 @@ def test_surrounded_cloud_feeds_set_map_on_device(gpu, oracle):
     assert s == rc == 0 and max(synth.pose_error(pg, po)) < 1e-7
     for k in grids:
         grids[k][0].close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(5))
+def test_grid_store_randomised(gpu, oracle, seed):
+    """Differential fuzzing of the map store: random clouds with negative coordinates, points exactly on cell
+    and voxel boundaries, duplicates and empty inserts, interleaved with surrounded-cloud queries at random
+    poses; every dump and query must equal the oracle's bit for bit."""
+    from msf_loam_amd import capi
+    rng = np.random.default_rng(9000 + seed)
+    leaf = float(rng.choice([0.2, 0.4, 1.0]))
+    go, gg = oracle.HybridGrid(3.0, leaf), capi.Grid(gpu, 3.0, leaf)
+    for step in range(6):
+        n = int(rng.integers(0, 3000)) if step != 2 else 0
+        pts = np.zeros((n, 4), np.float32)
+        pts[:, :3] = rng.uniform(-40, 40, (n, 3)) * np.array([1, 1, 0.15])
+        k = n // 6
+        if k:
+            pts[:k, :3] = np.round(pts[:k, :3] / 1.5) * 1.5              # cell boundaries (lround at .5) and voxel boundaries
+            pts[k:2 * k, :3] = np.round(pts[k:2 * k, :3] / leaf) * leaf
+            pts[2 * k:3 * k] = pts[:k]                                   # duplicates
+        pts[:, 3] = rng.uniform(0, 0.1, n)
+        assert go.insert_scan(pts) == 0
+        gg.insert_scan(pts)
+        assert gg.size() == go.size(), (seed, step)
+        assert np.array_equal(gg.dump(), go.dump()), (seed, step)
+        q = np.zeros((int(rng.integers(1, 400)), 4), np.float32)
+        q[:, :3] = rng.uniform(-30, 30, (len(q), 3)) * np.array([1, 1, 0.1])
+        q[0, :3] = [70, 0, 0]                                            # beyond the 60 m cut (:474)
+        pose = synth.random_poses(1, 9100 + 10 * seed + step)[0]
+        assert np.array_equal(gg.get_surrounded(q, pose), go.get_surrounded(q, pose)), (seed, step)
+    gg.close()
