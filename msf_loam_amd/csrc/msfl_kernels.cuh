@@ -594,7 +594,11 @@ constexpr int kOdomLmBlock = MSFL_ODOM_LM_BLOCK;               // scan-to-scan: 
 // one wavefront per problem, no cross-wave barrier)
 constexpr int lm_edge_cache(int block) { return block == 256 ? MSFL_LM_EDGE_CACHE : 0; }      // 60 B each
 constexpr int lm_plane_cache(int block) {
+#ifdef MSFL_LM_PLANE_CACHE
+  return block == 256 ? MSFL_LM_PLANE_CACHE : block == 128 ? 832 : 384;
+#else
   return block == 256 ? ((1728 - (lm_edge_cache(256) * 60 + 43) / 44) & ~63) : block == 128 ? 832 : 384;
+#endif
 }
 template <int BLOCK>
 struct PlaneCache {
@@ -945,8 +949,11 @@ __device__ __noinline__ int tr_decide(TrState& tr, const double* red, const Solv
 // Lane 0 runs the (serial, tiny) trust-region logic between evaluation passes; every pass
 // evaluates cost AND the normal equations at the candidate, so an accepted step needs no second
 // pass (Ceres re-evaluates; the values are identical).
+#ifndef MSFL_LM_WAVES
+#define MSFL_LM_WAVES 2
+#endif
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 2)
+__global__ void __launch_bounds__(BLOCK, MSFL_LM_WAVES)
 lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const double* __restrict__ rec_all,
                 double* __restrict__ poses, int* __restrict__ status, DevMatchInfo* __restrict__ info,
                 int outer_it, SolverParams prm) {
