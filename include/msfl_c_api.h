@@ -239,6 +239,24 @@ msfl_status msfl_match_scan2map_deskew(msfl_handle* h,
                                        const msfl_deskew* deskew,
                                        double pose_io[7], msfl_match_info* info);
 
+/* The deskew branch for a batch.  The four per-feature arrays are indexed exactly like the feature arrays
+   (corner feature corner_off[b] + k of scan b uses corner_dq[4 * (corner_off[b] + k)] ...), velocity holds
+   one Vi per scan; all follow `mem`. */
+typedef struct msfl_deskew_batch {
+  const double* corner_dq;  /* (corner_off[n_scans]) x 4 */
+  const double* corner_dp;  /* ... x 3 */
+  const double* surf_dq;
+  const double* surf_dp;
+  const double* velocity;   /* n_scans x 3 */
+  double gravity[3];
+} msfl_deskew_batch;
+
+msfl_status msfl_match_scan2map_deskew_batch(msfl_handle* h, int n_scans,
+                                             const msfl_point* corner, const int* corner_off,
+                                             const msfl_point* surf, const int* surf_off,
+                                             const msfl_deskew_batch* deskew,
+                                             double* poses_io, int* status, msfl_match_info* info, msfl_mem mem);
+
 /* ------------------------------------------------------------------------------------------ */
 /* stage B — scan-to-scan registration                                                        */
 /*   replaces OdometryScanMatcher::MatchScan2Scan (odometry_scan_matcher.h:10-12, .cc:43-285)  */

@@ -19,6 +19,7 @@ EXPORTED = [
     "msfl_default_params", "msfl_api_version", "msfl_create", "msfl_destroy", "msfl_set_stream", "msfl_reset_stream",
     "msfl_synchronize", "msfl_status_string", "msfl_last_error", "msfl_set_timing", "msfl_get_timing",
     "msfl_set_map", "msfl_match_scan2map", "msfl_match_scan2map_batch", "msfl_match_scan2map_deskew",
+    "msfl_match_scan2map_deskew_batch",
     "msfl_associate_scan2map", "msfl_solve_records",
     "msfl_match_scan2scan", "msfl_match_scan2scan_batch", "msfl_extract_features",
     "msfl_extract_features_batch", "msfl_voxel_downsample", "msfl_voxel_downsample_batch", "msfl_transform_cloud",
@@ -69,6 +70,11 @@ class Timing(C.Structure):
 class Deskew(C.Structure):
     _fields_ = [("corner_dq", C.c_void_p), ("corner_dp", C.c_void_p), ("surf_dq", C.c_void_p),
                 ("surf_dp", C.c_void_p), ("velocity", C.c_double * 3), ("gravity", C.c_double * 3)]
+
+
+class DeskewBatch(C.Structure):
+    _fields_ = [("corner_dq", C.c_void_p), ("corner_dp", C.c_void_p), ("surf_dq", C.c_void_p),
+                ("surf_dp", C.c_void_p), ("velocity", C.c_void_p), ("gravity", C.c_double * 3)]
 
 
 class RingCloud(C.Structure):
@@ -229,6 +235,28 @@ class Handle:
         s = self.lib.msfl_match_scan2map_batch(self.h, C.c_int(B), _vp(corner_ptr), _vp(co), _vp(surf_ptr), _vp(so),
                                                _vp(poses_ptr), _vp(status_ptr), None, C.c_int(MEM_DEVICE))
         self._check(s, "msfl_match_scan2map_batch(device)")
+
+    def match_scan2map_deskew_batch(self, corner, corner_off, surf, surf_off, corner_dq, corner_dp, surf_dq, surf_dp,
+                                    velocity, gravity, poses, mem=MEM_HOST, status=None):
+        """Deskew branch for B scans.  Host memory: numpy arrays in, (poses, status) out.  Device memory: pass
+        tensors / pointers (poses updated in place, `status` a device int32 buffer or None)."""
+        co = np.ascontiguousarray(corner_off, dtype=np.int32)
+        so = np.ascontiguousarray(surf_off, dtype=np.int32)
+        B = len(co) - 1
+        d = DeskewBatch()
+        if mem == MEM_HOST:
+            corner, surf = _pts(corner), _pts(surf)
+            keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (corner_dq, corner_dp, surf_dq, surf_dp, velocity)]
+            poses = np.array(poses, dtype=np.float64).reshape(-1, 7).copy()
+            status = np.zeros(B, np.int32)
+        else:
+            keep = [corner_dq, corner_dp, surf_dq, surf_dp, velocity]
+        d.corner_dq, d.corner_dp, d.surf_dq, d.surf_dp, d.velocity = (_vp(a).value for a in keep)
+        d.gravity = (C.c_double * 3)(*[float(g) for g in gravity])
+        s = self.lib.msfl_match_scan2map_deskew_batch(self.h, C.c_int(B), _vp(corner), _vp(co), _vp(surf), _vp(so), C.byref(d),
+                                                      _vp(poses), _vp(status), None, C.c_int(mem))
+        self._check(s, "msfl_match_scan2map_deskew_batch")
+        return poses, status
 
     def associate_scan2map(self, corner, surf, pose):
         """One data-association pass at `pose`: (n_corner+n_surf, 6) records {C, N}."""

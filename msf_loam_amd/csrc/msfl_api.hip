@@ -112,7 +112,7 @@ struct msfl_handle_s {
   DevBuf in_corner, in_surf, in_off, poses, status, info, records, pprime, nn;
   DevBuf idx_cell_of, idx_count, idx_bbox, idx_cub, idx_stage;
   size_t idx_count_zero = 0;   // leading ints of idx_count known to be zero on the stream
-  DevBuf dk[4];
+  DevBuf dk[5];
   DevBuf ex[16];
   DevBuf od[16];
   DevBuf vb[14];  // batched voxel filter
@@ -547,7 +547,7 @@ msfl_status msfl_set_map(msfl_handle* h, const msfl_point* corner, int n_corner,
 
 static msfl_status match_batch_impl(msfl_handle* h, int B, const msfl_point* corner, const int* corner_off,
                                     const msfl_point* surf, const int* surf_off, double* poses_io, int* status,
-                                    msfl_match_info* info, msfl_mem mem, const msfl_deskew* deskew) {
+                                    msfl_match_info* info, msfl_mem mem, const msfl_deskew_batch* deskew) {
   if (B < 0 || (B > 0 && (!corner_off || !surf_off || !poses_io)))
     return fail(h, MSFL_BAD_ARG, "msfl_match_scan2map_batch: null argument");
   if (B == 0) return MSFL_OK;
@@ -588,17 +588,23 @@ static msfl_status match_batch_impl(msfl_handle* h, int B, const msfl_point* cor
   }
   DeskewView dv{}; const DeskewView* dvp = nullptr;
   if (deskew) {
-    // host pointers only (documented); stage the four arrays
-    const size_t nb[4] = {(size_t)ncp * 4, (size_t)ncp * 3, (size_t)nsp * 4, (size_t)nsp * 3};
-    const double* src[4] = {deskew->corner_dq, deskew->corner_dp, deskew->surf_dq, deskew->surf_dp};
-    for (int k = 0; k < 4; k++) {
+    // the four per-feature arrays are indexed like the feature arrays (corner_off / surf_off), velocity per scan
+    const double* src[5] = {deskew->corner_dq, deskew->corner_dp, deskew->surf_dq, deskew->surf_dp, deskew->velocity};
+    const size_t nb[5] = {(size_t)ncp * 4, (size_t)ncp * 3, (size_t)nsp * 4, (size_t)nsp * 3, (size_t)B * 3};
+    const size_t skip[5] = {(size_t)c0 * 4, (size_t)c0 * 3, (size_t)s0 * 4, (size_t)s0 * 3, 0};
+    const double* dev[5];
+    for (int k = 0; k < 5; k++) {
       if (nb[k] && !src[k]) return fail(h, MSFL_BAD_ARG, "msfl_match_scan2map_deskew: null deskew array");
-      HIPCHK(h, h->dk[k].reserve(std::max<size_t>(1, nb[k]) * sizeof(double)));
-      if (nb[k]) HIPCHK(h, hipMemcpyAsync(h->dk[k].p, src[k], nb[k] * sizeof(double), hipMemcpyHostToDevice, st));
+      if (mem == MSFL_MEM_HOST) {
+        HIPCHK(h, h->dk[k].reserve(std::max<size_t>(1, nb[k]) * sizeof(double)));
+        if (nb[k]) HIPCHK(h, hipMemcpyAsync(h->dk[k].p, src[k] + skip[k], nb[k] * sizeof(double), hipMemcpyHostToDevice, st));
+        dev[k] = h->dk[k].as<double>();
+      } else {
+        dev[k] = src[k];
+      }
     }
-    dv.corner_dq = h->dk[0].as<double>(); dv.corner_dp = h->dk[1].as<double>();
-    dv.surf_dq = h->dk[2].as<double>(); dv.surf_dp = h->dk[3].as<double>();
-    for (int a = 0; a < 3; a++) { dv.V[a] = deskew->velocity[a]; dv.G[a] = deskew->gravity[a]; }
+    dv.corner_dq = dev[0]; dv.corner_dp = dev[1]; dv.surf_dq = dev[2]; dv.surf_dp = dev[3]; dv.V = dev[4];
+    for (int a = 0; a < 3; a++) dv.G[a] = deskew->gravity[a];
     dvp = &dv;
   }
   s = match_scan2map_device(h, B, d_corner, co.data(), d_surf, so.data(), d_poses, d_status, d_info, dvp);
@@ -637,9 +643,21 @@ msfl_status msfl_match_scan2map_deskew(msfl_handle* h, const msfl_point* corner,
   if (n_corner < 0 || n_surf < 0 || !pose_io || !deskew) return fail(h, MSFL_BAD_ARG, "msfl_match_scan2map_deskew: bad argument");
   const int co[2] = {0, n_corner}, so[2] = {0, n_surf};
   int st = 0;
-  s = match_batch_impl(h, 1, corner, co, surf, so, pose_io, &st, info, MSFL_MEM_HOST, deskew);
+  msfl_deskew_batch db;
+  db.corner_dq = deskew->corner_dq; db.corner_dp = deskew->corner_dp; db.surf_dq = deskew->surf_dq; db.surf_dp = deskew->surf_dp;
+  db.velocity = deskew->velocity;
+  for (int a = 0; a < 3; a++) db.gravity[a] = deskew->gravity[a];
+  s = match_batch_impl(h, 1, corner, co, surf, so, pose_io, &st, info, MSFL_MEM_HOST, &db);
   if (s) return s;
   return (msfl_status)st;
+}
+
+msfl_status msfl_match_scan2map_deskew_batch(msfl_handle* h, int n_scans, const msfl_point* corner, const int* corner_off,
+                                             const msfl_point* surf, const int* surf_off, const msfl_deskew_batch* deskew,
+                                             double* poses_io, int* status, msfl_match_info* info, msfl_mem mem) {
+  msfl_status s = enter(h); if (s) return s;
+  if (!deskew) return fail(h, MSFL_BAD_ARG, "msfl_match_scan2map_deskew_batch: null deskew");
+  return match_batch_impl(h, n_scans, corner, corner_off, surf, surf_off, poses_io, status, info, mem, deskew);
 }
 
 static msfl_status stage_single(msfl_handle* h, const msfl_point* corner, int n_corner, const msfl_point* surf, int n_surf,

@@ -392,7 +392,8 @@ struct DeskewView {
   // all null for the plain (LiDAR-only) branch
   const double* corner_dq; const double* corner_dp;
   const double* surf_dq;   const double* surf_dp;
-  double V[3], G[3];
+  const double* V;          // n_scans x 3 (device): Vi of every scan
+  double G[3];
   double* pprime;           // out: n_records x 3, p' = dq*p + dp
 };
 
@@ -425,8 +426,9 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
     quat dq; dq.x = dqp[0]; dq.y = dqp[1]; dq.z = dqp[2]; dq.w = dqp[3];
     const d3 dp = mk3(dpp[0], dpp[1], dpp[2]);
     const double dt = (double)f.w;
-    const d3 shift = mk3(dv.V[0] * dt - 0.5 * dv.G[0] * dt * dt, dv.V[1] * dt - 0.5 * dv.G[1] * dt * dt,
-                         dv.V[2] * dt - 0.5 * dv.G[2] * dt * dt);
+    const double* Vb = dv.V + 3 * (size_t)b;
+    const d3 shift = mk3(Vb[0] * dt - 0.5 * dv.G[0] * dt * dt, Vb[1] * dt - 0.5 * dv.G[1] * dt * dt,
+                         Vb[2] * dt - 0.5 * dv.G[2] * dt * dt);
     quat qc; qc.x = -T.q.x; qc.y = -T.q.y; qc.z = -T.q.z; qc.w = T.q.w;
     pose7 full;
     full.t = quat_rotate(T.q, quat_rotate(qc, shift) + dp) + T.t;       // Rigid3d operator*
@@ -479,8 +481,9 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
       // C' = C - (Vi dt - G dt^2/2): the velocity block is constant (mapping_scan_matcher.cc:94)
       const int fi = is_edge ? bv.corner_off[b] + local : bv.surf_off[b] + (local - nc);
       const double dt = (double)(is_edge ? bv.corner[fi].w : bv.surf[fi].w);
-      fo.C = fo.C - mk3(dv.V[0] * dt - 0.5 * dv.G[0] * dt * dt, dv.V[1] * dt - 0.5 * dv.G[1] * dt * dt,
-                        dv.V[2] * dt - 0.5 * dv.G[2] * dt * dt);
+      const double* Vb = dv.V + 3 * (size_t)b;
+      fo.C = fo.C - mk3(Vb[0] * dt - 0.5 * dv.G[0] * dt * dt, Vb[1] * dt - 0.5 * dv.G[1] * dt * dt,
+                        Vb[2] * dt - 0.5 * dv.G[2] * dt * dt);
     }
   }
   const size_t base = rec_base(bv, b);

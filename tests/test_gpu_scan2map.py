@@ -161,6 +161,44 @@ def test_deskew_variant_matches_oracle(gpu, oracle):
         assert synth.pose_error(p0, p1)[0] < 1e-12
 
 
+def test_deskew_batch_equals_single_calls_host_and_device(gpu, oracle):
+    """msfl_match_scan2map_deskew_batch: per-scan velocities, per-feature (dq, dp) indexed like the features;
+    every scan reproduces its single-scan call bit for bit, from host and from device memory."""
+    import torch
+    from msf_loam_amd import capi
+    _, mc, ms = common.small_world()
+    gpu.set_map(mc, ms)
+    rng = np.random.default_rng(33)
+    G = np.array([0.0, 0.0, 9.81])
+    items = []
+    for i, (pts, ring, truth, guess) in enumerate(common.scans(3)):
+        _, corner, surf = common.features_from_oracle(oracle, pts, ring)
+        V = np.array([0.8, -0.3, 0.05]) * (i + 1) / 2
+        def dqdp(cloud, k=i):
+            t = cloud[:, 3].astype(np.float64)
+            dq = np.stack([synth.quat_from_rotvec(r) for r in np.outer(t, [0.02, -0.01, 0.1 * (k + 1)])])
+            return dq, np.outer(t, [0.05, 0.02, -0.01]) + rng.normal(0, 1e-4, (len(t), 3))
+        items.append((corner, surf, *dqdp(corner), *dqdp(surf), V, guess))
+    co = np.cumsum([0] + [len(it[0]) for it in items]).astype(np.int32)
+    so = np.cumsum([0] + [len(it[1]) for it in items]).astype(np.int32)
+    cat = lambda k: np.concatenate([it[k] for it in items])
+    guesses = np.stack([it[7] for it in items]); vel = np.stack([it[6] for it in items])
+    poses, status = gpu.match_scan2map_deskew_batch(cat(0), co, cat(1), so, cat(2), cat(3), cat(4), cat(5), vel, G, guesses)
+    assert np.all(status == 0)
+    for b, it in enumerate(items):
+        s, p, _ = gpu.match_scan2map_deskew(it[0], it[1], it[2], it[3], it[4], it[5], it[6], G, it[7])
+        assert s == 0 and np.array_equal(p, poses[b]), b
+    rc, pose_o, _ = oracle.match_scan2map_deskew(mc, ms, *items[1][:6], items[1][6], G, items[1][7])
+    assert rc == 0 and max(synth.pose_error(poses[1], pose_o)) < TIGHT
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (cat(0), cat(1), cat(2), cat(3), cat(4), cat(5), vel, guesses)]
+    d_status = torch.zeros(3, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    gpu.match_scan2map_deskew_batch(t[0], co, t[1], so, t[2], t[3], t[4], t[5], t[6], G, t[7], mem=capi.MEM_DEVICE, status=d_status)
+    gpu.synchronize()
+    assert np.array_equal(t[7].cpu().numpy(), poses) and np.all(d_status.cpu().numpy() == 0)
+
+
 def test_lattice_map_with_ties_and_duplicates(gpu, oracle):
     """Exact-kNN stress: a lattice map (many exactly equal f32 distances), duplicated points, queries on
     lattice nodes, on cell boundaries of the index and exactly on / just inside / just outside the
