@@ -106,6 +106,7 @@ struct msfl_handle_s {
   bool have_map = false;
   MapIndex map_c, map_s;
   int grid_cap_cells = 64 * 1024 * 1024;  // hard limit of the dense cell table (MSFL_GRID_CAP_CELLS)
+  int h2d_chunk_scans = 512;              // MSFL_H2D_CHUNK_SCANS: scans per PCIe chunk of a host-buffer batch (>= 2 chunks to pipeline)
   bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)
 
   // scratch
@@ -119,6 +120,8 @@ struct msfl_handle_s {
   DevBuf pp[5];   // per-point passes: pre-integration samples, staged points, dq, dp, flag
 
   PinRing pin;
+  hipStream_t copy_stream = nullptr;      // host-buffer batches: H2D of chunk k+1 under the compute of chunk k
+  hipEvent_t copy_ev[9] = {};             // [8] = fork event
 
   // timing
   int timing = 0;            // 0 off, 1 every kernel class, 2 the association (5-NN) kernel only
@@ -419,6 +422,7 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
   }
   h->stream = h->own_stream;
   if (const char* e = std::getenv("MSFL_GRID_CAP_CELLS")) { const int c = std::atoi(e); if (c >= 8 && c <= (1 << 28)) h->grid_cap_cells = c; }
+  if (const char* e = std::getenv("MSFL_H2D_CHUNK_SCANS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_chunk_scans = c; }
   if (const char* e = std::getenv("MSFL_ODOM_BRUTE")) h->odom_force_brute = std::atoi(e) != 0;
   *out = h;
   return MSFL_OK;
@@ -441,6 +445,7 @@ void msfl_destroy(msfl_handle* h) {
   collect_timing(h);
   for (auto e : h->free_events) (void)hipEventDestroy(e);
   h->pin.release();
+  if (h->copy_stream) { (void)hipStreamDestroy(h->copy_stream); for (auto e : h->copy_ev) if (e) (void)hipEventDestroy(e); }
   for (MapIndex* mi : {&h->map_c, &h->map_s}) {
     if (mi->want_pending) (void)hipEventSynchronize(mi->want_ev);
     if (mi->want_ev) (void)hipEventDestroy(mi->want_ev);
@@ -559,12 +564,17 @@ static msfl_status match_batch_impl(msfl_handle* h, int B, const msfl_point* cor
     return fail(h, MSFL_BAD_ARG, "msfl_match_scan2map_batch: bad offsets or null feature array");
   const float4* d_corner; const float4* d_surf; double* d_poses; int* d_status;
   std::vector<int> co(corner_off, corner_off + B + 1), so(surf_off, surf_off + B + 1);
+  // Host buffers, large batch, plain branch: the features go over PCIe in chunks of >= 512 scans on a second
+  // stream while the previous chunk is being registered (82 MB per 1 024 scans is as long as the compute).
+  const int n_chunks = (mem == MSFL_MEM_HOST && !deskew && B >= 2 * h->h2d_chunk_scans) ? std::min(8, B / h->h2d_chunk_scans) : 1;
   if (mem == MSFL_MEM_HOST) {
     HIPCHK(h, h->in_corner.reserve(std::max<size_t>(1, (size_t)ncp) * sizeof(float4)));
     HIPCHK(h, h->in_surf.reserve(std::max<size_t>(1, (size_t)nsp) * sizeof(float4)));
     HIPCHK(h, h->poses.reserve((size_t)B * 7 * sizeof(double)));
-    if (ncp) HIPCHK(h, hipMemcpyAsync(h->in_corner.p, corner + c0, (size_t)ncp * sizeof(float4), hipMemcpyHostToDevice, st));
-    if (nsp) HIPCHK(h, hipMemcpyAsync(h->in_surf.p, surf + s0, (size_t)nsp * sizeof(float4), hipMemcpyHostToDevice, st));
+    if (n_chunks == 1) {
+      if (ncp) HIPCHK(h, hipMemcpyAsync(h->in_corner.p, corner + c0, (size_t)ncp * sizeof(float4), hipMemcpyHostToDevice, st));
+      if (nsp) HIPCHK(h, hipMemcpyAsync(h->in_surf.p, surf + s0, (size_t)nsp * sizeof(float4), hipMemcpyHostToDevice, st));
+    }
     HIPCHK(h, hipMemcpyAsync(h->poses.p, poses_io, (size_t)B * 7 * sizeof(double), hipMemcpyHostToDevice, st));
     for (int b = 0; b <= B; b++) { co[b] -= c0; so[b] -= s0; }
     d_corner = h->in_corner.as<float4>(); d_surf = h->in_surf.as<float4>(); d_poses = h->poses.as<double>();
@@ -607,8 +617,29 @@ static msfl_status match_batch_impl(msfl_handle* h, int B, const msfl_point* cor
     for (int a = 0; a < 3; a++) dv.G[a] = deskew->gravity[a];
     dvp = &dv;
   }
-  s = match_scan2map_device(h, B, d_corner, co.data(), d_surf, so.data(), d_poses, d_status, d_info, dvp);
-  if (s) return s;
+  if (n_chunks == 1) {
+    s = match_scan2map_device(h, B, d_corner, co.data(), d_surf, so.data(), d_poses, d_status, d_info, dvp);
+    if (s) return s;
+  } else {
+    if (!h->copy_stream) {
+      HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+      for (auto& e : h->copy_ev) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    // the staging buffers may still be read by work queued earlier on the compute stream
+    HIPCHK(h, hipEventRecord(h->copy_ev[8], st));
+    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->copy_ev[8], 0));
+    for (int c = 0; c < n_chunks; c++) {
+      const int b0 = (int)((long long)B * c / n_chunks), b1 = (int)((long long)B * (c + 1) / n_chunks);
+      const size_t nc = (size_t)(co[b1] - co[b0]), ns = (size_t)(so[b1] - so[b0]);
+      if (nc) HIPCHK(h, hipMemcpyAsync(h->in_corner.as<float4>() + co[b0], corner + c0 + co[b0], nc * sizeof(float4), hipMemcpyHostToDevice, h->copy_stream));
+      if (ns) HIPCHK(h, hipMemcpyAsync(h->in_surf.as<float4>() + so[b0], surf + s0 + so[b0], ns * sizeof(float4), hipMemcpyHostToDevice, h->copy_stream));
+      HIPCHK(h, hipEventRecord(h->copy_ev[c], h->copy_stream));
+      HIPCHK(h, hipStreamWaitEvent(st, h->copy_ev[c], 0));
+      s = match_scan2map_device(h, b1 - b0, d_corner, co.data() + b0, d_surf, so.data() + b0, d_poses + 7 * (size_t)b0, d_status + b0,
+                                d_info ? d_info + b0 : nullptr, nullptr);
+      if (s) return s;
+    }
+  }
   if (mem == MSFL_MEM_HOST) {
     HIPCHK(h, hipMemcpyAsync(poses_io, d_poses, (size_t)B * 7 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (status) HIPCHK(h, hipMemcpyAsync(status, d_status, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
