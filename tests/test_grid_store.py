@@ -1,6 +1,8 @@
 """N1: the local map store (HybridGrid, hybrid_grid.cc:462-534).
 CPU: the oracle against an independent numpy formulation.  GPU: msfl_grid_* against the oracle,
 bit for bit (same cell assignment, same voxel order, same f32 accumulation order)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -129,7 +131,7 @@ def test_surrounded_cloud_feeds_set_map_on_device(gpu, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MSFL_FUZZ_SEEDS", "5"))))
 def test_grid_store_randomised(gpu, oracle, seed):
     """Differential fuzzing of the map store: random clouds with negative coordinates, points exactly on cell
     and voxel boundaries, duplicates and empty inserts, interleaved with surrounded-cloud queries at random
