@@ -25,6 +25,15 @@ def test_cpp_host_mirror_compiles_and_links():
     _build()
 
 
+def test_header_is_plain_c_and_links():
+    """include/msfl_c_api.h through gcc -std=c99: what a cgo / JNI / N-API binding generator sees."""
+    _build()
+    exe = os.path.join(ROOT, "tests", "cpp", "c_header_check")
+    assert os.path.exists(exe)
+    out = subprocess.check_output([exe]).decode()         # pure host calls: default params, API version, symbol addresses
+    assert "20 entry points" in out and "sizeof(msfl_point)=16" in out
+
+
 @pytest.mark.gpu
 def test_cpp_host_mirror_matches_ctypes_path(gpu, tmp_path):
     _build()
