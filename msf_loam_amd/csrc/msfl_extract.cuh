@@ -369,7 +369,6 @@ __global__ void __launch_bounds__(256) extract_pick_kernel(ExtractView v, Extrac
     if (lane == 0) { v.status[b] = 7 /*MSFL_CAPACITY*/; cnt_out[0] = cnt_out[1] = cnt_out[2] = cnt_out[3] = 0; }
     return;
   }
-  const float* curv = v.curvature + o;
   uint8_t* label = v.label + o;
   const uint8_t* gapb = v.gap + o;
   int* t_sharp = v.tmp_idx + 0 * (size_t)v.n_total + o + s;
