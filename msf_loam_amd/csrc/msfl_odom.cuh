@@ -337,6 +337,7 @@ struct OdomIndex {
   const float4* sorted;      // targets in column order: xyz + (ring << 24 | index within the pair's cloud)
   const OdomPairDesc* desc;
   const int* mode;           // per pair: 0 = column grid, 1 = brute force
+  int tiles;                 // workgroups per pair in the query kernel
 };
 
 __global__ void __launch_bounds__(1024)
@@ -459,12 +460,21 @@ template <int L>
 __global__ void __launch_bounds__(256)
 assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const double* __restrict__ poses,
                                   const int* __restrict__ status, double* __restrict__ rec) {
-  const int b = blockIdx.x;
+  // XCD-aware block -> (pair, tile) mapping.  Workgroups are dealt round-robin to the 8 XCDs (block i -> XCD i % 8)
+  // and every XCD has its own L2: all `tiles` workgroups of a pair are given ids with the same residue mod 8 and
+  // consecutive quotients, so one XCD reads that pair's 0.5 MB of sorted targets + column table once instead of
+  // every XCD re-reading it at a different time (PMC per launch: FETCH_SIZE 1.72 -> 0.35 GB, L2 hit rate 31 -> 86 %;
+  // the kernel time only moved by 4 %: it is VALU / latency bound, the misses were hidden by 8 waves/SIMD).
+  const int tiles = ix.tiles;
+  const int group = blockIdx.x / (8 * tiles), within = blockIdx.x - group * (8 * tiles);
+  const int b = group * 8 + (within & 7);
+  const int tile = within >> 3;
+  if (b >= bv.n_scans) return;
   if (ix.mode[b] != 0) return;                                   // brute-force kernel owns this pair
   const int n_sharp = bv.corner_off[b + 1] - bv.corner_off[b];
   const int n_flat = bv.surf_off[b + 1] - bv.surf_off[b];
   const int sl = threadIdx.x % L;
-  const int qf = blockIdx.y * (256 / L) + threadIdx.x / L;
+  const int qf = tile * (256 / L) + threadIdx.x / L;
   if (qf >= n_flat) return;
   double* out = rec + rec_base(bv, b) + 6 * (size_t)n_sharp + 4 * (size_t)qf;
   const int s0 = ov.last_lf_off[b], s1 = ov.last_lf_off[b + 1];

@@ -9,6 +9,8 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --cpu-sample 0 $*"
+# PMC_CMD overrides the profiled command (default: the bench workload), e.g. PMC_CMD="python tools/stage_throughput.py 1024"
+CMD=${PMC_CMD:-"python $ROOT/bench.py $ARGS"}
 i=0
 for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" \
            "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
@@ -17,7 +19,7 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "WRITE_SIZE" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT -o pass$i -- python $ROOT/bench.py $ARGS > $OUT/pass$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT -o pass$i -- $CMD > $OUT/pass$i.log 2>&1
 done
 python $ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 du -sh $OUT/* | sort -h | tail -5
