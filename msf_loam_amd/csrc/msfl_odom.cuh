@@ -429,9 +429,24 @@ __device__ __forceinline__ void odom_walk(const OdomIndex& ix, const unsigned* _
   const int x0 = max(cx - r, 0), x1 = min(cx + r, W - 1);
   const int y0 = max(cy - r, 0), y1 = min(cy + r, H - 1);
   if (x0 > x1 || y0 > y1) return;
+  // row-major table: the run of columns [x0, x1] of a row ends where column x1 + 1 starts; the two loads are
+  // uniform inside the lane group (one transaction)
+  if (y1 - y0 <= 2) {
+    // the common 3x3 walk: all six run bounds are requested before the first run is read, so their latency
+    // is paid once instead of once per row
+    int b0[3], b1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int y = min(y0 + k, y1);
+      b0[k] = (int)tab[y * W + x0]; b1[k] = (int)tab[y * W + x1 + 1];
+      if (y0 + k > y1) b1[k] = b0[k];                       // fewer than three rows: an empty run
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      for (int i = b0[k] + sl; i < b1[k]; i += L) f(sorted[i]);
+    return;
+  }
   for (int y = y0; y <= y1; y++) {
-    // row-major table: the run of columns [x0, x1] ends where column x1 + 1 starts; the two loads are
-    // uniform inside the lane group (one transaction)
     const int b0 = (int)tab[y * W + x0], b1 = (int)tab[y * W + x1 + 1];
     for (int i = b0 + sl; i < b1; i += L) f(sorted[i]);
   }
