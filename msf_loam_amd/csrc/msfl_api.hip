@@ -115,7 +115,7 @@ struct msfl_handle_s {
   size_t idx_count_zero = 0;   // leading ints of idx_count known to be zero on the stream
   DevBuf dk[5];
   DevBuf ex[16];
-  DevBuf od[16];
+  DevBuf od[20];
   DevBuf vb[14];  // batched voxel filter
   DevBuf pp[5];   // per-point passes: pre-integration samples, staged points, dq, dp, flag
 

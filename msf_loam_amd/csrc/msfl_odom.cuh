@@ -42,7 +42,7 @@ __device__ __forceinline__ float odom_dist(float4 a, float3 q) {
 // bv.corner = curr sharp, bv.surf = curr flat; records in feature order (sharp first).
 __global__ void __launch_bounds__(256)
 assoc_scan2scan_kernel(BatchView bv, OdomView ov, const double* __restrict__ poses, const int* __restrict__ status,
-                       double* __restrict__ rec, const int* __restrict__ plane_mode) {
+                       double* __restrict__ rec, const int* __restrict__ plane_mode, const int* __restrict__ edge_mode) {
   __shared__ float4 s_tile[kOdomTile];
   const int b = blockIdx.y;
   const int n_sharp = bv.corner_off[b + 1] - bv.corner_off[b];
@@ -61,18 +61,19 @@ assoc_scan2scan_kernel(BatchView bv, OdomView ov, const double* __restrict__ pos
   }
   // plane_mode[b] == 0: the column-grid kernel below owns this pair's plane queries
   const bool planes_here = plane_mode == nullptr || plane_mode[b] != 0;
-  const bool is_edge = has_q && qi < n_sharp;
-  const bool is_plane = has_q && !is_edge && planes_here;
+  const bool edges_here = edge_mode == nullptr || edge_mode[b] != 0;       // likewise for the edge queries
+  const bool is_edge = has_q && qi < n_sharp && edges_here;
+  const bool is_plane = has_q && qi >= n_sharp && planes_here;
   float4 f = make_float4(0, 0, 0, 0);
   float3 q = make_float3(0, 0, 0);
-  if (has_q) {
+  if (is_edge || is_plane) {               // queries owned by the grid kernels are not touched here
     f = is_edge ? bv.corner[bv.corner_off[b] + qi] : bv.surf[bv.surf_off[b] + (qi - n_sharp)];
     const pose7 T = load_pose(poses + 7 * b);
     q = transform_point_f32(T, f.x, f.y, f.z);        // TransformToStart with s = 1 (:21-33)
   }
   const float thr = (float)ov.dist_sq_threshold;
   // which target clouds does this workgroup need? (uniform)
-  const bool wg_has_edge = q0 < n_sharp;
+  const bool wg_has_edge = q0 < n_sharp && edges_here;
   const bool wg_has_plane = (q0 + 256 > n_sharp) && (nq > n_sharp) && planes_here;
   int closest = -1, min2 = -1, min3 = -1;
 
@@ -471,10 +472,12 @@ __device__ __forceinline__ unsigned long long group_min_key(unsigned long long k
   return k;
 }
 
-template <int L>
+// EDGE = false: flat queries against the less-flat cloud (:166-258); EDGE = true: sharp queries against the
+// less-sharp cloud (:81-163: second point only from rings (id, id + 2.5] above / [id - 2.5, id) below).
+template <int L, bool EDGE>
 __global__ void __launch_bounds__(256)
-assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const double* __restrict__ poses,
-                                  const int* __restrict__ status, double* __restrict__ rec) {
+assoc_scan2scan_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const double* __restrict__ poses,
+                            const int* __restrict__ status, double* __restrict__ rec) {
   // XCD-aware block -> (pair, tile) mapping.  Workgroups are dealt round-robin to the 8 XCDs (block i -> XCD i % 8)
   // and every XCD has its own L2: all `tiles` workgroups of a pair are given ids with the same residue mod 8 and
   // consecutive quotients, so one XCD reads that pair's 0.5 MB of sorted targets + column table once instead of
@@ -490,19 +493,21 @@ assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const
   const int n_flat = bv.surf_off[b + 1] - bv.surf_off[b];
   const int sl = threadIdx.x % L;
   const int qf = tile * (256 / L) + threadIdx.x / L;
-  if (qf >= n_flat) return;
-  double* out = rec + rec_base(bv, b) + 6 * (size_t)n_sharp + 4 * (size_t)qf;
-  const int s0 = ov.last_lf_off[b], s1 = ov.last_lf_off[b + 1];
-  const float4* tp = ov.last_lf + s0;
+  if (qf >= (EDGE ? n_sharp : n_flat)) return;
+  constexpr int kOut = EDGE ? 6 : 4;
+  double* out = rec + rec_base(bv, b) + (EDGE ? 6 * (size_t)qf : 6 * (size_t)n_sharp + 4 * (size_t)qf);
+  const int* t_off = EDGE ? ov.last_ls_off : ov.last_lf_off;
+  const int s0 = t_off[b], s1 = t_off[b + 1];
+  const float4* tp = (EDGE ? ov.last_ls : ov.last_lf) + s0;
   const float thr = (float)ov.dist_sq_threshold;
   bool ok = status[b] == 0 && s1 > s0;
   float3 q = make_float3(0, 0, 0);
   if (ok) {
-    const float4 f = bv.surf[bv.surf_off[b] + qf];
+    const float4 f = EDGE ? bv.corner[bv.corner_off[b] + qf] : bv.surf[bv.surf_off[b] + qf];
     q = transform_point_f32(load_pose(poses + 7 * b), f.x, f.y, f.z);
     ok = fabsf(q.x) < (float)(kOdomRange + 7) && fabsf(q.y) < (float)(kOdomRange + 7);   // also rejects NaN
   }
-  if (!ok) { if (sl < 4) out[sl] = 0.0; return; }
+  if (!ok) { if (sl < kOut) out[sl] = 0.0; return; }
   const float fx = floorf(q.x), fy = floorf(q.y);
   const OdomPairDesc pd = ix.desc[b];
   const int cx = (int)fx - pd.ox, cy = (int)fy - pd.oy;           // may lie outside [0, W) x [0, H): the walk clips
@@ -522,7 +527,7 @@ assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const
     kbest = group_min_key<L>(kbest);
     if (__uint_as_float((unsigned)(kbest >> 32)) < odom_gap_sq(q, fx, fy, r)) break;
   }
-  if (!(__uint_as_float((unsigned)(kbest >> 32)) < thr)) { if (sl < 4) out[sl] = 0.0; return; }       // :173 (NaN / none: not <)
+  if (!(__uint_as_float((unsigned)(kbest >> 32)) < thr)) { if (sl < kOut) out[sl] = 0.0; return; }    // :87 / :173 (NaN / none: not <)
   const int closest = (int)((unsigned)kbest & 0xffffffu), id = (int)((unsigned)kbest >> 24 & 0xffu);
   // ---- ring-window minima (:183-232): forward ties -> lowest index, backward ties -> highest index
   //      (tie word 0xffffff - index); tie word 0xffffffff = nothing found ----
@@ -539,17 +544,24 @@ assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const
       if (!(d < thr)) return;                                    // every running minimum starts at the 25 m^2 gate
       // branch-free updates (selects): branches here make the compiler address the minima through memory
       const bool fwd = j > closest, same = fwd ? rj <= id : rj >= id;
+      if (EDGE && same) return;                                  // edges take their second point from other rings only (:96, :121)
       const unsigned long long kd = (unsigned long long)__float_as_uint(d) << 32;
       const unsigned long long kf = kd | (unsigned)j, kb = kd | (unsigned)(0xffffff - j);
-      kf2 = (fwd && same && kf < kf2) ? kf : kf2;
-      kf3 = (fwd && !same && kf < kf3) ? kf : kf3;
-      kb2 = (!fwd && same && kb < kb2) ? kb : kb2;
-      kb3 = (!fwd && !same && kb < kb3) ? kb : kb3;
+      if (EDGE) {                                                // the second point of an edge plays the role of min2
+        kf2 = (fwd && kf < kf2) ? kf : kf2;
+        kb2 = (!fwd && kb < kb2) ? kb : kb2;
+      } else {
+        kf2 = (fwd && same && kf < kf2) ? kf : kf2;
+        kf3 = (fwd && !same && kf < kf3) ? kf : kf3;
+        kb2 = (!fwd && same && kb < kb2) ? kb : kb2;
+        kb3 = (!fwd && !same && kb < kb3) ? kb : kb3;
+      }
     });
-    kf2 = group_min_key<L>(kf2); kf3 = group_min_key<L>(kf3); kb2 = group_min_key<L>(kb2); kb3 = group_min_key<L>(kb3);
+    kf2 = group_min_key<L>(kf2); kb2 = group_min_key<L>(kb2);
+    if (!EDGE) { kf3 = group_min_key<L>(kf3); kb3 = group_min_key<L>(kb3); }
     const float g = odom_gap_sq(q, fx, fy, r);
     const float m2 = __uint_as_float((unsigned)((kf2 < kb2 ? kf2 : kb2) >> 32)), m3 = __uint_as_float((unsigned)((kf3 < kb3 ? kf3 : kb3) >> 32));
-    if (m2 < g && m3 < g) break;
+    if (m2 < g && (EDGE || m3 < g)) break;
   }
   if (sl != 0) return;
   const float f2 = __uint_as_float((unsigned)(kf2 >> 32)), f3 = __uint_as_float((unsigned)(kf3 >> 32));
@@ -559,6 +571,16 @@ assoc_scan2scan_plane_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const
   const int min2 = (jb2 >= 0 && b2 < f2) ? jb2 : jf2;           // backward continues the forward minimum with strict '<'
   const int min3 = (jb3 >= 0 && b3 < f3) ? jb3 : jf3;
   d3 C = mk3(0, 0, 0), N = mk3(0, 0, 0);
+  if (EDGE) {
+    if (min2 >= 0) {                                             // :143-162
+      const float4 a = tp[closest], c = tp[min2];
+      const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z);
+      N = normalized(A - Bp);
+      C = A;
+    }
+    out[0] = C.x; out[1] = C.y; out[2] = C.z; out[3] = N.x; out[4] = N.y; out[5] = N.z;
+    return;
+  }
   if (min2 >= 0 && min3 >= 0) {                                  // :234-256, lidar_factor.h:70-78
     const float4 a = tp[closest], c = tp[min2], e = tp[min3];
     const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z),
