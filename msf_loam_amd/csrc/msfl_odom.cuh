@@ -443,8 +443,14 @@ __device__ __forceinline__ void odom_walk(const OdomIndex& ix, const unsigned* _
       if (y0 + k > y1) b1[k] = b0[k];                       // fewer than three rows: an empty run
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++)
-      for (int i = b0[k] + sl; i < b1[k]; i += L) f(sorted[i]);
+    for (int k = 0; k < 3; k++) {
+      int i = b0[k] + sl;
+      for (; i + L < b1[k]; i += 2 * L) {                     // two loads in flight per lane
+        const float4 p0 = sorted[i], p1 = sorted[i + L];
+        f(p0); f(p1);
+      }
+      if (i < b1[k]) f(sorted[i]);
+    }
     return;
   }
   for (int y = y0; y <= y1; y++) {
