@@ -445,11 +445,11 @@ __device__ __forceinline__ void odom_walk(const OdomIndex& ix, const unsigned* _
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       int i = b0[k] + sl;
-      for (; i + L < b1[k]; i += 2 * L) {                     // two loads in flight per lane
-        const float4 p0 = sorted[i], p1 = sorted[i + L];
-        f(p0); f(p1);
+      for (; i + 3 * L < b1[k]; i += 4 * L) {                 // four loads in flight per lane
+        const float4 p0 = sorted[i], p1 = sorted[i + L], p2 = sorted[i + 2 * L], p3 = sorted[i + 3 * L];
+        f(p0); f(p1); f(p2); f(p3);
       }
-      if (i < b1[k]) f(sorted[i]);
+      for (; i < b1[k]; i += L) f(sorted[i]);
     }
     return;
   }
