@@ -502,10 +502,13 @@ __global__ void __launch_bounds__(256) extract_compact_kernel(ExtractView v, con
 #pragma unroll
   for (int L = 0; L < 4; L++) {
     const int* tmp = v.tmp_idx + (size_t)L * v.n_total + o;
-    for (int r = 0; r < kMaxRings; r++) {
-      const int c = cnt[r * 4 + L];
-      const int dst = s_pref[L][r], src = tab[r];
-      for (int k = tid; k < c; k += 256) outs[L][dst + k] = tmp[src + k];
+    // one flat loop over the output positions; the owning ring comes from a 7-step search in the LDS prefix
+    // (instead of 128 per-ring loops, most of them over empty or 2-entry lists)
+    const int total = s_pref[L][kMaxRings];
+    for (int k = tid; k < total; k += 256) {
+      int lo = 0, hi = kMaxRings;                    // largest r with s_pref[L][r] <= k and a non-empty list
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[L][mid] <= k) lo = mid; else hi = mid; }
+      outs[L][k] = tmp[tab[lo] + (k - s_pref[L][lo])];
     }
   }
   // TransformPointCloudInPlace x5 (:367-371): the five clouds are gathers of the full cloud
