@@ -421,53 +421,86 @@ __global__ void __launch_bounds__(256) extract_pick_kernel(ExtractView v, Extrac
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (lane == 0) {
+    {
+      // The reference walks the sorted sector one candidate at a time; here the wave looks at 64 candidates at once
+      // (every lane tests its own candidate's `picked` bit), takes the first unpicked one in curvature order, marks
+      // its neighbourhood and looks again: one round per PICK (<= 20 + 4 per sector) instead of one per candidate.
       const unsigned long long* keys = in_lds ? s_keys[wave] : gkeys;
       // corner picks, descending curvature (:272-305)
       int largest = 0;
-      for (int k = cnt - 1; k >= 0; k--) {
-        const unsigned long long key = keys[k];
+      bool done = false;
+      for (int base = 0; base < cnt && !done; base += 64) {
+        const int k = cnt - 1 - (base + lane);
+        const bool have = k >= 0;
+        const unsigned long long key = have ? keys[k] : 0ull;
         const int ind = (int)(unsigned int)key;
-        const float c = __uint_as_float((unsigned int)(key >> 32));
-        if (!((double)c > prm.curvature_threshold)) break;   // sorted: nothing below can qualify
         const int q = ind - s;
-        if (picked.get(q)) continue;
-        largest++;
-        if (largest <= prm.max_sharp) {
-          label[ind] = 1; t_sharp[n_sharp++] = ind; t_ls[n_ls++] = ind;
-        } else if (largest <= prm.max_less_sharp) {
-          label[ind] = 2; t_ls[n_ls++] = ind;
-        } else {
-          break;
+        const bool qual = have && ((double)__uint_as_float((unsigned int)(key >> 32)) > prm.curvature_threshold);
+        // sorted: the first non-qualifying candidate ends the pass (:275), so only the lanes before it count
+        const unsigned long long nq = __ballot(!qual);
+        const unsigned long long upto = nq ? ((1ull << (__ffsll((long long)nq) - 1)) - 1ull) : ~0ull;
+        if (nq) done = true;
+        for (;;) {
+          const bool unp = qual && !picked.get(q);
+          const unsigned long long m = __ballot(unp) & upto;
+          if (m == 0) break;
+          const int L = __ffsll((long long)m) - 1;
+          const int pind = __shfl(ind, L), pq = pind - s;
+          largest++;
+          if (largest > prm.max_less_sharp) { done = true; break; }            // :283-285 (no marking for this one)
+          int back, fwd;
+          neighbour_span(gap, pq, back, fwd);                  // runs of |p[i+1]-p[i]|^2 <= 0.05 around the pick
+          if (lane == 0) {
+            if (largest <= prm.max_sharp) { label[pind] = 1; t_sharp[n_sharp] = pind; t_ls[n_ls] = pind; }
+            else { label[pind] = 2; t_ls[n_ls] = pind; }
+            const unsigned int span = (2u << (back + fwd)) - 1u;   // back + fwd + 1 ones
+            picked.or_window(pq - back, span); corner.or_window(pq - back, span);
+          }
+          if (largest <= prm.max_sharp) n_sharp++;
+          n_ls++;
+          if (lane >= 1 && lane <= back) label[pind - lane] = 2;   // relabel the neighbours (:295, :302)
+          if (lane >= 1 && lane <= fwd) label[pind + lane] = 2;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        int back, fwd;
-        neighbour_span(gap, q, back, fwd);                   // runs of |p[i+1]-p[i]|^2 <= 0.05 around q
-        const unsigned int span = (2u << (back + fwd)) - 1u; // back + fwd + 1 ones
-        picked.or_window(q - back, span); corner.or_window(q - back, span);
-        for (int l = -back; l <= fwd; l++) if (l != 0) label[ind + l] = 2;
       }
       // flat picks, ascending curvature (:307-336)
       int smallest = 0;
-      for (int k = 0; k < cnt; k++) {
-        const unsigned long long key = keys[k];
+      done = false;
+      for (int base = 0; base < cnt && !done; base += 64) {
+        const int k = base + lane;
+        const bool have = k < cnt;
+        const unsigned long long key = have ? keys[k] : 0ull;
         const int ind = (int)(unsigned int)key;
-        const float c = __uint_as_float((unsigned int)(key >> 32));
-        if (!((double)c < prm.curvature_threshold)) break;
         const int q = ind - s;
-        if (picked.get(q)) continue;
-        label[ind] = 3; t_flat[n_flat++] = ind;
-        smallest++;
-        if (smallest >= prm.max_flat) break;                 // before neighbour marking, :317-319
-        int back, fwd;
-        neighbour_span(gap, q, back, fwd);
-        picked.or_window(q - back, (2u << (back + fwd)) - 1u);
+        const bool qual = have && ((double)__uint_as_float((unsigned int)(key >> 32)) < prm.curvature_threshold);
+        const unsigned long long nq = __ballot(!qual);
+        const unsigned long long upto = nq ? ((1ull << (__ffsll((long long)nq) - 1)) - 1ull) : ~0ull;
+        if (nq) done = true;
+        for (;;) {
+          const bool unp = qual && !picked.get(q);
+          const unsigned long long m = __ballot(unp) & upto;
+          if (m == 0) break;
+          const int L = __ffsll((long long)m) - 1;
+          const int pind = __shfl(ind, L), pq = pind - s;
+          if (lane == 0) { label[pind] = 3; t_flat[n_flat] = pind; }
+          n_flat++;
+          smallest++;
+          if (smallest >= prm.max_flat) { done = true; break; }    // before neighbour marking, :317-319
+          int back, fwd;
+          neighbour_span(gap, pq, back, fwd);
+          if (lane == 0) picked.or_window(pq - back, (2u << (back + fwd)) - 1u);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // less-flat = positions of this sector not labelled SHARP / LESS_SHARP so far (:338-344)
-    n_lf = __shfl(n_lf, 0);
     for (int k0 = sp; k0 <= ep; k0 += 64) {
       const int k = k0 + lane;
       const bool keep = (k <= ep) && !corner.get(k - s);
