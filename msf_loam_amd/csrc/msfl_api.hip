@@ -57,7 +57,9 @@ struct PinRing {
     if (s.pending) { e = hipEventSynchronize(s.ev); if (e != hipSuccess) return e; s.pending = false; }
     if (bytes > s.cap) {
       if (s.p) { e = hipHostFree(s.p); if (e != hipSuccess) return e; s.p = nullptr; s.cap = 0; }
-      size_t want = (std::max<size_t>(bytes, 4096) + 4095) & ~size_t(4095);
+      // generous floor: growing a slot later costs a hipHostFree + hipHostMalloc (tens of milliseconds, and it
+      // happened once per slot as soon as a (B+1)-int offset table of a 1 024-scan batch met a 4 KB slot)
+      size_t want = (std::max<size_t>(bytes, 256 * 1024) + 4095) & ~size_t(4095);
       e = hipHostMalloc(&s.p, want, hipHostMallocDefault); if (e != hipSuccess) return e;
       s.cap = want;
     }
@@ -76,6 +78,22 @@ struct PinRing {
       s = PinSlot{};
     }
   }
+};
+
+// Pinned host buffer for small synchronous read-backs (counts, offsets, descriptors): a D2H copy into pageable
+// memory goes through the runtime's staging path, which stalls for tens of milliseconds once in a while.
+struct PinBuf {
+  void* p = nullptr; size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipHostFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    const size_t want = (std::max<size_t>(bytes, 4096) + 4095) & ~size_t(4095);
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
 struct MapIndex {
@@ -120,6 +138,7 @@ struct msfl_handle_s {
   DevBuf pp[5];   // per-point passes: pre-integration samples, staged points, dq, dp, flag
 
   PinRing pin;
+  PinBuf readback;
   hipStream_t copy_stream = nullptr;      // host-buffer batches: H2D of chunk k+1 under the compute of chunk k
   hipEvent_t copy_ev[9] = {};             // [8] = fork event
 
@@ -445,6 +464,7 @@ void msfl_destroy(msfl_handle* h) {
   collect_timing(h);
   for (auto e : h->free_events) (void)hipEventDestroy(e);
   h->pin.release();
+  h->readback.release();
   if (h->copy_stream) { (void)hipStreamDestroy(h->copy_stream); for (auto e : h->copy_ev) if (e) (void)hipEventDestroy(e); }
   for (MapIndex* mi : {&h->map_c, &h->map_s}) {
     if (mi->want_pending) (void)hipEventSynchronize(mi->want_ev);

@@ -11,6 +11,8 @@ h = capi.Handle(0)
 inp = bench.build_inputs(1024, 200000, 0, extractor=bench.product_extractor(h))
 h.set_map(inp["map_corner"], inp["map_surf"])
 co, so = inp["corner_off"], inp["surf_off"]
+import gc
+gc.collect(); gc.disable()
 res = {}
 for label, pin in (("pageable", False), ("pinned", True)):
     c, s, g = inp["corner"], inp["surf"], inp["guesses"]

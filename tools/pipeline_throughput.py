@@ -105,6 +105,8 @@ def whole():
 
 whole()                                                     # warm-up (allocations)
 whole()
+import gc
+gc.collect(); gc.disable()                                   # a gen-2 collection of this harness is a ~40 ms pause
 t_ext, t_vox, t_reg = timed(extract, STEPS), timed(voxel, STEPS), timed(register, STEPS)
 t_ext2 = timed(extract, STEPS)
 t_all = timed(whole, STEPS)
