@@ -98,7 +98,7 @@ struct PinBuf {
 
 struct MapIndex {
   DevBuf gdesc;        // GridDesc, computed on the device (no host round trip in msfl_set_map)
-  DevBuf bbox;         // 6 ordered ints, armed once and re-armed by grid_setup_kernel
+  DevBuf bbox;         // 6 ordered ints, armed once and re-armed by grid_scatter_kernel (grid_setup_kernel for an empty cloud)
   int cap_cells = 0;   // capacity of cell_start / count (cells)
   // feedback for the table span of the next build (asynchronous read-back, never waited for)
   int* want_host = nullptr; hipEvent_t want_ev = nullptr; bool want_pending = false; int span = 0;
@@ -243,17 +243,18 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   HIPCHK(h, mi.sorted.reserve(std::max<size_t>(1, (size_t)n) * sizeof(float4)));
   HIPCHK(h, mi.pos_of.reserve(std::max<size_t>(1, (size_t)n) * sizeof(int)));
   mi.cap_cells = cap;
-  if (!mi.bbox.p) {                       // armed once; grid_setup_kernel re-arms it after every read
+  if (!mi.bbox.p) {                       // armed once; the build re-arms it after the last read
     HIPCHK(h, mi.bbox.reserve(6 * sizeof(int)));
     const int init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
     HIPCHK(h, h->pin.upload(mi.bbox.p, init, sizeof(init), st));
   }
   if (n > 0) {
-    const int blocks = std::min(div_up(n, 256), 64);   // few blocks: the 6 atomics per wave contend on one line
+    const int blocks = std::min(div_up(n, 1024), 256);   // 6 atomics per workgroup, all on one line: four points per lane and pass
     hipLaunchKernelGGL(grid_bbox_kernel, dim3(blocks), dim3(256), 0, st, pts, n, mi.bbox.as<int>());
   }
-  hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1), 0, st, mi.bbox.as<int>(),
-                     std::sqrt((double)h->prm.map_knn_max_sq_dist), cap, mi.gdesc.as<GridDesc>());
+  const double radius = std::sqrt((double)h->prm.map_knn_max_sq_dist);
+  if (n == 0)
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1), 0, st, mi.bbox.as<int>(), radius, cap, mi.gdesc.as<GridDesc>());
   // the table is cleared / scanned over the cells actually used last time (+ margin) when known,
   // else over the full capacity; the device never indexes beyond n_cells <= cap.
   const size_t span = (size_t)cap + 1;
@@ -263,8 +264,8 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   h->idx_count_zero = 0;                  // unknown until this build has been enqueued completely
   if (span > zeroed) HIPCHK(h, hipMemsetAsync(h->idx_count.p, 0, span * sizeof(int), st));
   if (n > 0)
-    hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, (const GridDesc*)mi.gdesc.as<GridDesc>(),
-                       h->idx_cell_of.as<int>(), h->idx_count.as<int>());
+    hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, (const int*)mi.bbox.as<int>(), radius, cap,
+                       mi.gdesc.as<GridDesc>(), h->idx_cell_of.as<int>(), h->idx_count.as<int>());
   size_t tmp_bytes = 0;
   HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(), (int)span, st));
   HIPCHK(h, h->idx_cub.reserve(tmp_bytes));
@@ -272,7 +273,7 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   if (n > 0)
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, h->idx_cell_of.as<int>(),
                        mi.cell_start.as<int>(), h->idx_count.as<int>(), mi.sorted.as<float4>(), mi.pos_of.as<int>(),
-                       mi.gdesc.as<GridDesc>());
+                       mi.gdesc.as<GridDesc>(), mi.bbox.as<int>());
   HIPCHK(h, hipGetLastError());
   h->idx_count_zero = std::max(zeroed, span);
   if (!mi.want_pending) {

@@ -58,14 +58,21 @@ __host__ __device__ __forceinline__ float ordered_to_float(int i) {
 
 // bbox[0..2] = min (ordered ints), bbox[3..5] = max; pre-initialised to INT_MAX / INT_MIN
 __global__ void __launch_bounds__(256) grid_bbox_kernel(const float4* __restrict__ pts, int n, int* __restrict__ bbox) {
+  __shared__ float s_mn[4][3], s_mx[4][3];
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float4 p = pts[i];
+  auto take = [&](float4 p) {
     if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
       mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
       mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
     }
+  };
+  const int stride = gridDim.x * blockDim.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {       // four independent loads in flight per lane
+    const float4 p0 = pts[i], p1 = pts[i + stride], p2 = pts[i + 2 * stride], p3 = pts[i + 3 * stride];
+    take(p0); take(p1); take(p2); take(p3);
   }
+  for (; i < n; i += stride) take(pts[i]);
 #pragma unroll
   for (int a = 0; a < 3; a++) {
 #pragma unroll
@@ -74,14 +81,21 @@ __global__ void __launch_bounds__(256) grid_bbox_kernel(const float4* __restrict
       mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
     }
   }
-  if ((threadIdx.x & 63) == 0) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      if (mn[a] <= mx[a]) {
-        atomicMin(&bbox[a], float_to_ordered(mn[a]));
-        atomicMax(&bbox[3 + a], float_to_ordered(mx[a]));
-      }
-    }
+    for (int a = 0; a < 3; a++) { s_mn[wave][a] = mn[a]; s_mx[wave][a] = mx[a]; }
+  }
+  __syncthreads();
+  // six lanes, one atomic each per workgroup (they all land on one cache line: keep them few)
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    const float v = fminf(fminf(s_mn[0][a], s_mn[1][a]), fminf(s_mn[2][a], s_mn[3][a]));
+    if (v != INFINITY) atomicMin(&bbox[a], float_to_ordered(v));
+  } else if (threadIdx.x < 6) {
+    const int a = threadIdx.x - 3;
+    const float v = fmaxf(fmaxf(s_mx[0][a], s_mx[1][a]), fmaxf(s_mx[2][a], s_mx[3][a]));
+    if (v != -INFINITY) atomicMax(&bbox[3 + a], float_to_ordered(v));
   }
 }
 
@@ -92,22 +106,19 @@ __device__ __forceinline__ int grid_coord(float v, float o, float inv, int dim) 
   return (int)u;
 }
 
-// One thread: bbox -> grid descriptor, entirely on the device so that msfl_set_map needs no host
-// round trip.  Cell edge = 1.001 * acceptance radius, grown by 26 % steps until the dense table fits
-// `cap_cells` (larger cells stay exact).  An empty cloud yields n_cells = 1, n_pts = 0.
-// `bbox` is re-armed (INT_MAX / INT_MIN) for the next build once it has been read.
-__global__ void grid_setup_kernel(int* __restrict__ bbox, double radius, int cap_cells, GridDesc* __restrict__ out) {
+// bbox -> grid descriptor, entirely on the device so that msfl_set_map needs no host round trip.
+// Cell edge = 1.001 * acceptance radius, grown by 26 % steps until the dense table fits `cap_cells`
+// (larger cells stay exact).  An empty cloud yields n_cells = 1, n_pts = 0.
+__device__ __forceinline__ GridDesc grid_desc_from_bbox(const int* __restrict__ bbox, double radius, int cap_cells) {
   GridDesc g;
   const int b0 = bbox[0];
   g.n_pts = 0; g.reach = 1;
   if (b0 == 0x7fffffff) {            // no finite point
     g.ox = g.oy = g.oz = 0.f; g.inv_cell = 1.f; g.inv_cell_x = (float)kGridXSub; g.dx = g.dy = g.dz = 1; g.n_cells = 1; g.want_cells = 1;
-    *out = g;
-    return;
+    return g;
   }
   float mn[3], mx[3];
   for (int a = 0; a < 3; a++) { mn[a] = ordered_to_float(bbox[a]); mx[a] = ordered_to_float(bbox[3 + a]); }
-  for (int a = 0; a < 3; a++) { bbox[a] = 0x7fffffff; bbox[3 + a] = (int)0x80000000; }
   double cell = 1.001 * radius;
   int dims[3];
   bool first = true;
@@ -129,14 +140,34 @@ __global__ void grid_setup_kernel(int* __restrict__ bbox, double radius, int cap
   g.inv_cell_x = (float)((double)kGridXSub / cell);
   g.dx = dims[0]; g.dy = dims[1]; g.dz = dims[2];
   g.n_cells = g.dx * g.dy * g.dz;
-  *out = g;
+  return g;
 }
 
-__global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restrict__ pts, int n, const GridDesc* __restrict__ gp,
+__device__ __forceinline__ void grid_bbox_rearm(int* __restrict__ bbox) {
+  for (int a = 0; a < 3; a++) { bbox[a] = 0x7fffffff; bbox[3 + a] = (int)0x80000000; }
+}
+
+// Only launched for an EMPTY cloud (nothing else runs then); a non-empty build derives the descriptor
+// inside grid_count_kernel and re-arms the bbox in grid_scatter_kernel.
+__global__ void grid_setup_kernel(int* __restrict__ bbox, double radius, int cap_cells, GridDesc* __restrict__ out) {
+  *out = grid_desc_from_bbox(bbox, radius, cap_cells);
+  grid_bbox_rearm(bbox);
+}
+
+// Every workgroup derives the (identical) descriptor from the finished bbox itself: one launch less
+// per build than a separate one-thread setup kernel; workgroup 0 publishes it.
+__global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restrict__ pts, int n, const int* __restrict__ bbox,
+                                                          double radius, int cap_cells, GridDesc* __restrict__ gout,
                                                           int* __restrict__ cell_of, int* __restrict__ count) {
+  __shared__ GridDesc s_g;
+  if (threadIdx.x == 0) {
+    s_g = grid_desc_from_bbox(bbox, radius, cap_cells);
+    if (blockIdx.x == 0) *gout = s_g;
+  }
+  __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const GridDesc g = *gp;
+  const GridDesc g = s_g;
   const float4 p = pts[i];
   int c = -1;
   if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
@@ -156,9 +187,9 @@ __global__ void __launch_bounds__(256) grid_scatter_kernel(const float4* __restr
                                                             const int* __restrict__ cell_of,
                                                             const int* __restrict__ cell_start, int* __restrict__ cursor,
                                                             float4* __restrict__ sorted, int* __restrict__ pos_of,
-                                                            GridDesc* __restrict__ g) {
+                                                            GridDesc* __restrict__ g, int* __restrict__ bbox) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) g->n_pts = cell_start[g->n_cells];     // number of indexed (finite) points
+  if (i == 0) { g->n_pts = cell_start[g->n_cells]; grid_bbox_rearm(bbox); }     // number of indexed (finite) points; bbox ready for the next build
   if (i >= n) return;
   const int c = cell_of[i];
   if (c < 0) { pos_of[i] = -1; return; }
