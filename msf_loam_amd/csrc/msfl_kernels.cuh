@@ -604,6 +604,22 @@ __device__ __forceinline__ void huber_rho(double a, double s, double& rho0, doub
   }
 }
 
+// Plane rows: the robustifier's argument is s = r * r of ONE residual, and in binary floating point sqrt(fl(r * r)) == |r|
+// whenever r * r neither underflows nor overflows (checked on 2e8 random and full-mantissa doubles): inside the
+// outlier branch (s > delta^2) the first of the corrector's two square roots is therefore |r|, bit for bit.
+__device__ __forceinline__ void huber_rho_scalar(double a, double resid, double& rho0, double& rho1) {
+  const double b = a * a;
+  const double s = resid * resid;
+  if (s > b) {
+    double r = fabs(resid);
+    if (!(s <= 1.7976931348623157e308)) r = sqrt(s);      // overflowed square: keep the literal form
+    rho0 = 2.0 * a * r - b;
+    rho1 = fmax(2.2250738585072014e-308, a / r);
+  } else {
+    rho0 = s; rho1 = 1.0;
+  }
+}
+
 // One evaluation pass of a scan's records at pose T: cost, g = J^T r, H = J^T J (robustified,
 // tangent space).  lidar_factor.cc:7-44 + Ceres HuberLoss/Corrector.
 // LDS-resident copy of the first K plane records + their points (44 B each, structure of arrays so
@@ -727,7 +743,7 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
     if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) continue;      // rejected correspondence
     n_plane++;
     const double r = dot(N, lm_rotate(T.q, p) + T.t) - d0;
-    double rho0, rho1; huber_rho(huber, r * r, rho0, rho1);
+    double rho0, rho1; huber_rho_scalar(huber, r, rho0, rho1);
     acc[0] += 0.5 * rho0;
     acc_row(acc, R, p, N, r, sqrt(rho1));                      // :38-39
   }
