@@ -40,6 +40,7 @@ struct GridDesc {
   int n_cells;
   int reach;          // cells scanned on each side of the query cell (1)
   int want_cells;     // cells the bbox needs at the base cell edge (saturated); host feedback for the next build
+  float cell2, cellx2;  // (1 / inv_cell)^2 and (1 / inv_cell_x)^2 in f32: every query needs them, computed once per build
 };
 
 // order-preserving float <-> int encoding for atomicMin/Max
@@ -106,6 +107,11 @@ __device__ __forceinline__ int grid_coord(float v, float o, float inv, int dim) 
   return (int)u;
 }
 
+__device__ __forceinline__ void grid_desc_squares(GridDesc& g) {
+  const float cell = 1.0f / g.inv_cell, cellx = 1.0f / g.inv_cell_x;
+  g.cell2 = cell * cell; g.cellx2 = cellx * cellx;
+}
+
 // bbox -> grid descriptor, entirely on the device so that msfl_set_map needs no host round trip.
 // Cell edge = 1.001 * acceptance radius, grown by 26 % steps until the dense table fits `cap_cells`
 // (larger cells stay exact).  An empty cloud yields n_cells = 1, n_pts = 0.
@@ -115,6 +121,7 @@ __device__ __forceinline__ GridDesc grid_desc_from_bbox(const int* __restrict__ 
   g.n_pts = 0; g.reach = 1;
   if (b0 == 0x7fffffff) {            // no finite point
     g.ox = g.oy = g.oz = 0.f; g.inv_cell = 1.f; g.inv_cell_x = (float)kGridXSub; g.dx = g.dy = g.dz = 1; g.n_cells = 1; g.want_cells = 1;
+    grid_desc_squares(g);
     return g;
   }
   float mn[3], mx[3];
@@ -140,6 +147,7 @@ __device__ __forceinline__ GridDesc grid_desc_from_bbox(const int* __restrict__ 
   g.inv_cell_x = (float)((double)kGridXSub / cell);
   g.dx = dims[0]; g.dy = dims[1]; g.dz = dims[2];
   g.n_cells = g.dx * g.dy * g.dz;
+  grid_desc_squares(g);
   return g;
 }
 
@@ -274,13 +282,11 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
   const int cz = grid_coord(q.z, g.oz, g.inv_cell, g.dz);
   const int xs = max(cx - kGridXSub, 0), xe = min(cx + kGridXSub, g.dx - 1);
   if (xs > xe) return;
-  const float cell = 1.0f / g.inv_cell;
-  const float cell2 = cell * cell;
+  const float cell2 = g.cell2;
   // per-axis lower bounds for the three y and three z cell offsets, computed once
   const float gy0 = axis_gap(uy, cy - 1), gy1 = axis_gap(uy, cy), gy2 = axis_gap(uy, cy + 1);
   const float gz0 = axis_gap(uz, cz - 1), gz1 = axis_gap(uz, cz), gz2 = axis_gap(uz, cz + 1);
-  const float cellx = 1.0f / g.inv_cell_x;
-  const float cellx2 = cellx * cellx;
+  const float cellx2 = g.cellx2;
   // squared lower bounds of the kGridXSub cells left of / right of the query cell, outermost first: they
   // are the same for all nine rows, so the per-row trimming is two adds and two compares per side
   float gxa[kGridXSub], gxb[kGridXSub];
