@@ -79,12 +79,14 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
   __shared__ int s_first[16], s_badw[16];
   __shared__ int s_flag[2];
   __shared__ double s_start_ori;
+  __shared__ double s_lasta[16][kMaxRings];   // pass B: raw angle of the last point of (wave, ring) so far; NaN = none yet
+  __shared__ double s_firsta[16][kMaxRings];  // raw angle of the first point of (wave, ring)
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int o = v.off[b];
   const int n = v.off[b + 1] - o;
   const float4* in = v.in_pts + o;
   const uint16_t* in_ring = v.in_ring + o;
-  for (int k = tid; k < 16 * kMaxRings; k += 1024) (&s_cur[0][0])[k] = 0;
+  for (int k = tid; k < 16 * kMaxRings; k += 1024) { (&s_cur[0][0])[k] = 0; (&s_lasta[0][0])[k] = __longlong_as_double(0x7ff8000000000000ll); }
   __syncthreads();
   const int slice = ((n + 15) / 16 + 63) & ~63;            // multiple of 64: a 64-point group never straddles two waves
   const int w0 = min(wave * slice, n), w1 = min(w0 + slice, n);
@@ -148,8 +150,12 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
   const double two_pi = 2 * 3.14159265358979323846;
   float4* out_pts = v.full_pts + o;
   uint16_t* out_ring = v.full_ring + o;
-  double* rel = v.rel + o;
-  // ---- pass B: stable split into rings, every wave in its own slice, driver order ----
+  // ---- pass B: stable split into rings, every wave in its own slice, driver order.  The wrap test of the reference
+  //      (`relative_angle < last_relative_angles[ring]`, :145-149: from the first such point on a ring gets +2 pi) compares a
+  //      point with its predecessor ON ITS RING, which is the previous same-ring lane of the group, or the last same-ring
+  //      point this wave has seen (LDS), or the last one of an earlier wave (fixed up after the pass): the f64 raw angles
+  //      never go to memory.  Both candidate times are produced here; the wrapped one waits in `t1` ----
+  float* t1 = reinterpret_cast<float*>(v.rel + o);
   for (int g = w0; g < w1; g += 64) {
     const int i = g + lane;
     float4 p = make_float4(0, 0, 0, 0);
@@ -162,38 +168,61 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
     }
     int dst = 0;
     const unsigned long long m = same_ring_lanes(valid, r);
+    const unsigned long long below = m & ((1ull << lane) - 1ull);
+    double a = 0.0;
     if (valid) {
       const int cur = s_cur[wave][r];                        // every lane of a ring reads the cursor ...
-      dst = cur + __popcll(m & ((1ull << lane) - 1ull));
-      if (lane == __ffsll((long long)m) - 1) s_cur[wave][r] = cur + __popcll(m);   // ... before its leader advances it
-    }
-    if (valid) {
+      dst = cur + __popcll(below);
+      if (below == 0) s_cur[wave][r] = cur + __popcll(m);    // ... before its leader advances it
       const double ori = -atan2((double)p.y, (double)p.x);                 // :139
       // fmod(a, 2 pi) with a = ori - start_ori + 2 pi in [0, 4 pi]: fmod is exact and so is a - 2 pi for
       // 2 pi <= a <= 4 pi (Sterbenz), so two conditional subtractions give the same bits (:142)
-      double a = ori - start_ori + two_pi;
+      a = ori - start_ori + two_pi;
       if (a >= two_pi) a -= two_pi;
       if (a >= two_pi) a -= two_pi;
-      rel[dst] = a;
-      out_pts[dst] = make_float4(p.x, p.y, p.z, 0.f);
+    }
+    // predecessor on the ring inside this group: the highest same-ring lane below this one
+    const int pl = below ? 63 - __clzll((long long)below) : lane;
+    double a_prev = __shfl(a, pl);
+    if (valid) {
+      bool has_prev = below != 0;
+      if (!has_prev) {                                       // leader of its ring in this group: what the wave saw before
+        a_prev = s_lasta[wave][r];
+        has_prev = !isnan(a_prev);
+        if (!has_prev) s_firsta[wave][r] = a;
+      }
+      if ((m >> lane) == 1ull) s_lasta[wave][r] = a;         // last lane of the ring in this group (after the leader's read)
+      if (has_prev && a < a_prev) atomicMin(&s_wrap[r], dst);
+      const float t0 = (float)(a / two_pi * prm.scan_period);                        // :151
+      t1[dst] = (float)((a + two_pi) / two_pi * prm.scan_period);
+      out_pts[dst] = make_float4(p.x, p.y, p.z, t0);
       out_ring[dst] = (uint16_t)r;
     }
   }
   __syncthreads();
-  // P4: per ring, the first point whose raw angle is below its predecessor's: from there on the
-  // reference adds 2 pi (a prefix-OR of `relative_angle < last_relative_angles[ring]`, :145-149)
-  for (int i = tid; i < N; i += 1024) {
-    const int r = out_ring[i];
-    if (i > s_off[r] && rel[i] < rel[i - 1]) atomicMin(&s_wrap[r], i);
+  // predecessor in an earlier wave: the first point of (wave, ring) against the last point of the nearest earlier wave
+  // that holds the ring.  The ring's output range is split among the waves in order, so (wave, ring) starts where the
+  // previous wave's cursor ended.
+  if (tid < kMaxRings) {
+    const int r = tid;
+    int base = s_off[r];
+    bool has_prev = false;
+    double last = 0.0;
+    for (int w = 0; w < 16; w++) {
+      const int end = s_cur[w][r];
+      if (end > base) {
+        if (has_prev && s_firsta[w][r] < last) atomicMin(&s_wrap[r], base);
+        last = s_lasta[w][r];
+        has_prev = true;
+      }
+      base = end;
+    }
   }
   __syncthreads();
-  // P5: relative time (stored in both `time` and `intensity`, :152-153)
+  // relative time (stored in both `time` and `intensity`, :152-153): from a ring's wrap point on, the +2 pi candidate
   for (int i = tid; i < N; i += 1024) {
     const int r = out_ring[i];
-    double a = rel[i];
-    if (i >= s_wrap[r]) a += two_pi;
-    const double t = a / two_pi * prm.scan_period;                         // :151
-    out_pts[i].w = (float)t;
+    if (i >= s_wrap[r]) out_pts[i].w = t1[i];
   }
   if (tid == 0) v.n_full[b] = N;
 }
