@@ -92,18 +92,33 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
   const int w0 = min(wave * slice, n), w1 = min(w0 + slice, n);
   // ---- pass A: populations, first valid point, ring check ----
   int first = 0x7fffffff, bad = 0;
-  for (int g = w0; g < w1; g += 64) {
-    const int i = g + lane;
-    bool valid = false;
-    int r = -1;
-    if (i < w1) {
-      valid = point_valid(in[i], prm.min_range);
-      if (valid) { r = in_ring[i]; if (r >= kMaxRings) { bad = 1; valid = false; } }   // CHECK_LT(point.ring, 128), :136
+  // four 64-point groups per iteration with their loads issued up front: one workgroup per CU keeps 16 wavefronts
+  // there, and one 16-byte load per lane in flight is far from what HBM needs to stay busy
+  constexpr int kGroups = 4;
+  for (int g0 = w0; g0 < w1; g0 += 64 * kGroups) {
+    float4 pp[kGroups]; int rr[kGroups];
+#pragma unroll
+    for (int u = 0; u < kGroups; u++) {
+      const int i = g0 + 64 * u + lane;
+      pp[u] = make_float4(0, 0, 0, 0); rr[u] = 0;
+      if (i < w1) { pp[u] = in[i]; rr[u] = in_ring[i]; }
     }
-    const unsigned long long any_valid = __ballot(valid);
-    if (any_valid && first == 0x7fffffff) first = g + (__ffsll((long long)any_valid) - 1);
-    const unsigned long long m = same_ring_lanes(valid, r);
-    if (valid && lane == __ffsll((long long)m) - 1) s_cur[wave][r] += __popcll(m);     // one leader per distinct ring
+#pragma unroll
+    for (int u = 0; u < kGroups; u++) {
+      const int g = g0 + 64 * u;
+      if (g >= w1) break;
+      const int i = g + lane;
+      bool valid = false;
+      int r = -1;
+      if (i < w1) {
+        valid = point_valid(pp[u], prm.min_range);
+        if (valid) { r = rr[u]; if (r >= kMaxRings) { bad = 1; valid = false; } }   // CHECK_LT(point.ring, 128), :136
+      }
+      const unsigned long long any_valid = __ballot(valid);
+      if (any_valid && first == 0x7fffffff) first = g + (__ffsll((long long)any_valid) - 1);
+      const unsigned long long m = same_ring_lanes(valid, r);
+      if (valid && lane == __ffsll((long long)m) - 1) s_cur[wave][r] += __popcll(m);     // one leader per distinct ring
+    }
   }
   bad = __any(bad) ? 1 : 0;
   if (lane == 0) { s_first[wave] = first; s_badw[wave] = bad; }
@@ -156,15 +171,25 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
   //      point this wave has seen (LDS), or the last one of an earlier wave (fixed up after the pass): the f64 raw angles
   //      never go to memory.  Both candidate times are produced here; the wrapped one waits in `t1` ----
   float* t1 = reinterpret_cast<float*>(v.rel + o);
-  for (int g = w0; g < w1; g += 64) {
+  for (int g0 = w0; g0 < w1; g0 += 64 * kGroups) {
+    float4 pp[kGroups]; int rr[kGroups];
+#pragma unroll
+    for (int u = 0; u < kGroups; u++) {
+      const int i = g0 + 64 * u + lane;
+      pp[u] = make_float4(0, 0, 0, 0); rr[u] = 0;
+      if (i < w1) { pp[u] = in[i]; rr[u] = in_ring[i]; }
+    }
+#pragma unroll
+    for (int u = 0; u < kGroups; u++) {
+    const int g = g0 + 64 * u;
+    if (g >= w1) break;
     const int i = g + lane;
-    float4 p = make_float4(0, 0, 0, 0);
+    const float4 p = pp[u];
     int r = -1;
     bool valid = false;
     if (i < w1) {
-      p = in[i];
       valid = point_valid(p, prm.min_range);
-      if (valid) r = in_ring[i];
+      if (valid) r = rr[u];
     }
     int dst = 0;
     const unsigned long long m = same_ring_lanes(valid, r);
@@ -197,6 +222,7 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
       t1[dst] = (float)((a + two_pi) / two_pi * prm.scan_period);
       out_pts[dst] = make_float4(p.x, p.y, p.z, t0);
       out_ring[dst] = (uint16_t)r;
+    }
     }
   }
   __syncthreads();
