@@ -126,12 +126,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # test hook (1-GPU boxes): MSFL_BENCH_SHARED_GPU=1 puts every rank on cuda:0 and swaps RCCL for gloo, so that the
+    # N > 1 control flow (sharding by rank, pose gather, max-over-ranks timing, rank-0 reporting) can be exercised
+    # where only one GPU exists; the numbers of such a run mean nothing
+    shared_gpu = os.environ.get("MSFL_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = "RANK" in os.environ            # launched by torch.distributed.run (also exercises N=1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     from msf_loam_amd import capi, dist as mdist
     h = capi.Handle(local_rank)

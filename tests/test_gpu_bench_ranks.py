@@ -1,0 +1,29 @@
+"""bench.py's N > 1 control flow on a 1-GPU box: two ranks share cuda:0 over gloo (MSFL_BENCH_SHARED_GPU=1).
+Checks what the driver relies on: exactly one JSON line, from rank 0, whole-job value, no CPU baseline leg."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_ranks_print_one_whole_job_line():
+    env = dict(os.environ, MSFL_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scans", "64",
+           "--cpu-sample", "0"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["scaling"] == "weak" and d["config"]["scans_per_gpu"] == 64
+    # whole-job value: both ranks' registrations over the max-over-ranks time
+    assert abs(d["value"] - 2 * 64 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert d["cpu_baseline"] is None
+    assert d["n_failed"] == 0
