@@ -91,14 +91,15 @@ def cpu_baseline(inp, sample, threads):
     args = (inp["map_corner"], inp["map_surf"], inp["corner"][:co[-1]], co, inp["surf"][:so[-1]], so, inp["guesses"][:n])
     n1 = max(1, min(n, 16))
     t0 = time.perf_counter()
-    orc.match_scan2map_batch(args[0], args[1], inp["corner"][:co[n1]], co[:n1 + 1], inp["surf"][:so[n1]], so[:n1 + 1],
-                             inp["guesses"][:n1], threads=1, rebuild_tree_per_scan=True)
+    _, _, stages = orc.match_scan2map_batch_timed(args[0], args[1], inp["corner"][:co[n1]], co[:n1 + 1], inp["surf"][:so[n1]],
+                                                  so[:n1 + 1], inp["guesses"][:n1])
     t1 = time.perf_counter()
     single = n1 / (t1 - t0)
+    stages_ms = {k: 1e3 * v / n1 for k, v in stages.items()}          # per registration, one thread
     t0 = time.perf_counter()
     poses, status = orc.match_scan2map_batch(*args, threads=threads, rebuild_tree_per_scan=True)
     t1 = time.perf_counter()
-    return dict(value=n / (t1 - t0), single_thread_value=single, n=n, n_single=n1, poses=poses)
+    return dict(value=n / (t1 - t0), single_thread_value=single, n=n, n_single=n1, poses=poses, stages_ms=stages_ms)
 
 
 def main():
@@ -207,6 +208,13 @@ def main():
         step()
     barrier()
     timing_all = h.get_timing(reset=True)
+    # one more step with the counting 5-NN instantiation: map points whose distance was evaluated (SURVEY.md 8d's
+    # secondary figure; the HBM roofline is not what binds this kernel)
+    h.set_timing(3)
+    h.get_timing(reset=True)
+    step()
+    barrier()
+    knn_candidates = h.get_timing(reset=True).knn_candidates
     h.set_timing(0)
     gc.enable()
     if use_dist:
@@ -260,6 +268,10 @@ def main():
                            "note": "assoc: HIP events inside the timed region; fit / solve / index_build: 3 extra steps after it",
                            "launches": {"assoc": timing.launches_assoc, "solve": timing_all.launches_solve,
                                         "index": timing_all.launches_index}},
+            "knn": {"candidates_per_launch": knn_candidates // 2, "candidates_per_query": knn_candidates / 2 / max(F_total, 1),
+                    "distance_evals_per_s": (knn_candidates / 2) / (assoc_ms * 1e-3) if assoc_ms > 0 else 0.0,
+                    "note": "map points whose f32 distance one launch evaluates (counting instantiation, one extra step); "
+                            "rate = count / the timed launches' average duration"},
             "prep_s": t_prep,
             "n_failed": int((status_gpu != 0).sum()),
         }
@@ -274,6 +286,15 @@ def main():
                                              "kd-tree rebuild, OpenMP over scans on %d threads (single-thread figure on %d scans)"
                                              % (cb["n"], B, cores, cb["n_single"])}
             out["pose_delta_vs_oracle"] = {"max_m": max(dts), "max_rad": max(drs), "n": cb["n"], "tolerance": 1e-4}
+            # the reference's LOG_STEP_TIME stages (mapping_scan_matcher.cc:73,248,264,275), CPU port per registration on one
+            # thread next to the GPU's share of a batch divided by its scans
+            k = out["kernels_ms"]
+            gpu = {"build tree": k["index_build"] * 2, "Data association": 2 * (k["assoc"] + k["fit"]), "Solver time": 2 * k["solve"]}
+            cpu = dict(cb["stages_ms"])
+            for t in (gpu, cpu):
+                t["Optimization twice"] = t["Data association"] + t["Solver time"]
+            out["stages_MAP"] = {"cpu_port_ms_per_registration_1_thread": cpu,
+                                 "gpu_ms_per_batch": gpu, "gpu_us_per_registration": {n_: 1e3 * v / B for n_, v in gpu.items()}}
         print(json.dumps(out))
     h.close()
     if use_dist:

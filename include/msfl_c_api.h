@@ -124,6 +124,7 @@ typedef struct msfl_timing {
   int    launches_extract; double ms_extract;   /* feature extraction (all kernels)   */
   int    launches_odom;    double ms_odom;      /* scan-to-scan association kernel    */
   int    launches_fit;     double ms_fit;       /* line / plane fit kernel            */
+  unsigned long long knn_candidates;            /* map points whose distance the 5-NN kernel evaluated (mode 3 only) */
 } msfl_timing;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -154,7 +155,9 @@ const char* msfl_status_string(int status);
 const char* msfl_last_error(const msfl_handle* h);
 
 /* enabled: 0 off; 1 every kernel class; 2 only the association (5-NN) kernel — two events per launch
-   instead of two per class, for timing the dominant kernel inside a throughput measurement. */
+   instead of two per class, for timing the dominant kernel inside a throughput measurement; 3 like 1, and the
+   5-NN kernel additionally counts the candidates it evaluates (a counting instantiation: slower, for the
+   "distance evaluations per second" figure only). */
 msfl_status msfl_set_timing(msfl_handle* h, int enabled);
 msfl_status msfl_get_timing(msfl_handle* h, msfl_timing* out, int reset);
 

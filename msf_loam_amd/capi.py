@@ -64,7 +64,7 @@ class Timing(C.Structure):
                 ("launches_index", C.c_int), ("ms_index", C.c_double),
                 ("launches_extract", C.c_int), ("ms_extract", C.c_double),
                 ("launches_odom", C.c_int), ("ms_odom", C.c_double),
-                ("launches_fit", C.c_int), ("ms_fit", C.c_double)]
+                ("launches_fit", C.c_int), ("ms_fit", C.c_double), ("knn_candidates", C.c_ulonglong)]
 
 
 class Deskew(C.Structure):

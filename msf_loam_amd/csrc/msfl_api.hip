@@ -130,6 +130,7 @@ struct msfl_handle_s {
   // scratch
   DevBuf in_corner, in_surf, in_off, poses, status, info, records, pprime, nn;
   DevBuf idx_cell_of, idx_count, idx_bbox, idx_cub, idx_stage;
+  DevBuf knn_count;            // one u64: candidates evaluated by the counting 5-NN instantiation (timing mode 3)
   size_t idx_count_zero = 0;   // leading ints of idx_count known to be zero on the stream
   DevBuf dk[5];
   DevBuf ex[16];
@@ -173,7 +174,7 @@ hipEvent_t get_event(msfl_handle* h) {
 
 struct ScopedTimer {
   msfl_handle* h; TimedSpan s{}; bool on;
-  ScopedTimer(msfl_handle* h_, int cls) : h(h_), on(h_->timing == 1 || (h_->timing == 2 && cls == T_ASSOC)) {
+  ScopedTimer(msfl_handle* h_, int cls) : h(h_), on(h_->timing == 1 || h_->timing == 3 || (h_->timing == 2 && cls == T_ASSOC)) {
     if (on) { s.a = get_event(h); s.b = get_event(h); s.cls = cls; (void)hipEventRecord(s.a, h->stream); }
   }
   ~ScopedTimer() {
@@ -292,7 +293,21 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv, const double* d_poses, 
   const dim3 grid(div_up(n_rec, 256)), block(256);
   {
     ScopedTimer timer(h, T_ASSOC);
-    if (deskew)
+    if (h->timing == 3) {
+      unsigned long long* cnt = h->knn_count.as<unsigned long long>();
+      if (deskew)
+        hipLaunchKernelGGL((knn5_scan2map_kernel<true, true>), grid, block, 0, st, bv, d_poses, d_status,
+                           (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                           (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                           (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
+                           h->prm.map_knn_max_sq_dist, dv, nn, cnt);
+      else
+        hipLaunchKernelGGL((knn5_scan2map_kernel<false, true>), grid, block, 0, st, bv, d_poses, d_status,
+                           (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                           (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                           (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
+                           h->prm.map_knn_max_sq_dist, dv, nn, cnt);
+    } else if (deskew)
       hipLaunchKernelGGL(knn5_scan2map_kernel<true>, grid, block, 0, st, bv, d_poses, d_status,
                          (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
                          (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
@@ -475,7 +490,7 @@ void msfl_destroy(msfl_handle* h) {
   DevBuf* bufs[] = {&h->map_c.sorted, &h->map_c.cell_start, &h->map_s.sorted, &h->map_s.cell_start, &h->map_c.pos_of, &h->map_s.pos_of,
                     &h->map_c.gdesc, &h->map_s.gdesc, &h->map_c.bbox, &h->map_s.bbox, &h->in_corner,
                     &h->in_surf, &h->in_off, &h->poses, &h->status, &h->info, &h->records, &h->pprime, &h->nn,
-                    &h->idx_cell_of, &h->idx_count, &h->idx_bbox, &h->idx_cub, &h->idx_stage};
+                    &h->idx_cell_of, &h->idx_count, &h->idx_bbox, &h->idx_cub, &h->idx_stage, &h->knn_count};
   for (auto* b : bufs) b->release();
   for (auto& b : h->dk) b.release();
   for (auto& b : h->ex) b.release();
@@ -524,7 +539,11 @@ const char* msfl_last_error(const msfl_handle* h) { return h ? h->last_error.c_s
 
 msfl_status msfl_set_timing(msfl_handle* h, int enabled) {
   msfl_status s = enter(h); if (s) return s;
-  h->timing = enabled < 0 ? 0 : (enabled > 2 ? 1 : enabled);
+  h->timing = enabled < 0 ? 0 : (enabled > 3 ? 1 : enabled);
+  if (h->timing == 3 && !h->knn_count.p) {
+    HIPCHK(h, h->knn_count.reserve(sizeof(unsigned long long)));
+    HIPCHK(h, hipMemsetAsync(h->knn_count.p, 0, sizeof(unsigned long long), h->stream));
+  }
   return MSFL_OK;
 }
 
@@ -539,6 +558,11 @@ msfl_status msfl_get_timing(msfl_handle* h, msfl_timing* out, int reset) {
   out->launches_extract = h->t_n[T_EXTRACT]; out->ms_extract = h->t_ms[T_EXTRACT];
   out->launches_odom = h->t_n[T_ODOM];       out->ms_odom = h->t_ms[T_ODOM];
   out->launches_fit = h->t_n[T_FIT];         out->ms_fit = h->t_ms[T_FIT];
+  out->knn_candidates = 0;
+  if (h->knn_count.p) {
+    HIPCHK(h, hipMemcpy(&out->knn_candidates, h->knn_count.p, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(h, hipMemset(h->knn_count.p, 0, sizeof(unsigned long long)));
+  }
   if (reset) for (int i = 0; i < T_COUNT; i++) { h->t_ms[i] = 0; h->t_n[i] = 0; }
   return MSFL_OK;
 }

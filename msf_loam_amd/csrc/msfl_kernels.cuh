@@ -274,7 +274,8 @@ __device__ __forceinline__ float axis_gap(float u, int c) {
 }
 
 __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __restrict__ sorted,
-                                          const int* __restrict__ cell_start, float3 q, float max_sq_dist, Top5& t) {
+                                          const int* __restrict__ cell_start, float3 q, float max_sq_dist, Top5& t,
+                                          int& n_cand) {      // n_cand: candidates evaluated (dead code unless the caller reads it)
   top5_init(t, max_sq_dist);
   const float ux = (q.x - g.ox) * g.inv_cell_x, uy = (q.y - g.oy) * g.inv_cell, uz = (q.z - g.oz) * g.inv_cell;
   const int cx = grid_coord(q.x, g.ox, g.inv_cell_x, g.dx);
@@ -303,6 +304,7 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
   // candidates of the cells [a, b] of a row: x-adjacent cells are contiguous in the sorted array
   auto scan = [&](int row, int a, int b) __attribute__((always_inline)) {
     const int s = cell_start[row + a], e = cell_start[row + b + 1];
+    n_cand += e - s;
     const float4* p = sorted + s;
     const float4* const pe = sorted + e;
     for (; p + 1 < pe; p += 2) {            // two loads in flight, one address register
@@ -437,13 +439,13 @@ struct DeskewView {
 // K4a: transform + exact 5-NN.  Low register count (no f64 fits here) -> 8 waves/SIMD to hide the
 // latency of the scattered 16-byte candidate loads.  nn[5*g..] = positions in the sorted map (nearest first),
 // nn[5*g] = -1 when the feature is rejected by the `pointSearchSqDis[4] < 1.0` gate (:128 / :198).
-template <bool DESKEW>
+template <bool DESKEW, bool COUNT = false>
 __global__ void __launch_bounds__(256)
 knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
                      const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
                      const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
                      const int* __restrict__ pos_c, const int* __restrict__ pos_s,
-                     float max_sq_dist, DeskewView dv, int* __restrict__ nn) {
+                     float max_sq_dist, DeskewView dv, int* __restrict__ nn, unsigned long long* __restrict__ n_candidates = nullptr) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bv.n_records) return;
   const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);
@@ -477,8 +479,10 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
     q = transform_point_f32(T, f.x, f.y, f.z);                          // :123 / :193
   }
   Top5 t;
-  if (is_edge) { const GridDesc gc = *gcp; knn5_grid(gc, map_c, cs_c, q, max_sq_dist, t); }
-  else { const GridDesc gs = *gsp; knn5_grid(gs, map_s, cs_s, q, max_sq_dist, t); }
+  int n_cand = 0;
+  if (is_edge) { const GridDesc gc = *gcp; knn5_grid(gc, map_c, cs_c, q, max_sq_dist, t, n_cand); }
+  else { const GridDesc gs = *gsp; knn5_grid(gs, map_s, cs_s, q, max_sq_dist, t, n_cand); }
+  if (COUNT) atomicAdd(n_candidates, (unsigned long long)n_cand);
   if ((unsigned int)t.k4 != 0xffffffffu && (double)top5_d4(t) < (double)max_sq_dist) {      // :128 / :198
     // original map index -> position in the sorted map array (the fit kernel then gathers directly);
     // done here because this kernel runs at 8 waves/SIMD and hides the extra dependent load

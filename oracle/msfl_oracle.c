@@ -15,6 +15,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -719,17 +720,28 @@ void orc_associate_scan2map(const orc_point* map_corner, int mc, const orc_point
   orc_kdtree_free(tc); orc_kdtree_free(ts);
 }
 
-static int match_scan2map_trees(const orc_point* map_corner, int mc, const orc_kdtree* tc,
-                                const orc_point* map_surf, int ms, const orc_kdtree* ts,
-                                const orc_point* corner, int nc, const orc_point* surf, int ns,
-                                double pose[7], orc_match_info* info) {
+static double now_s(void) {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+/* stage_s (optional): seconds added to {Data association, Solver time}, the reference's LOG_STEP_TIME stages
+ * (mapping_scan_matcher.cc:248, :264) */
+static int match_scan2map_trees_timed(const orc_point* map_corner, int mc, const orc_kdtree* tc,
+                                      const orc_point* map_surf, int ms, const orc_kdtree* ts,
+                                      const orc_point* corner, int nc, const orc_point* surf, int ns,
+                                      double pose[7], orc_match_info* info, double* stage_s) {
   orc_solver_options opt;
   orc_default_solver_options(&opt);
   orc_corr* corr = (orc_corr*)malloc(sizeof(orc_corr) * (size_t)(nc + ns + 1));
   for (int it = 0; it < 2; it++) {                                   /* kOptimalNum, :75 */
+    const double t0 = stage_s ? now_s() : 0.0;
     associate_scan2map_trees(map_corner, mc, tc, map_surf, ms, ts, corner, nc, surf, ns, pose, corr);
+    const double t1 = stage_s ? now_s() : 0.0;
     orc_solve_summary s;
     orc_ceres_solve(corr, nc + ns, pose, &opt, &s);                  /* :259, write-back :271 */
+    if (stage_s) { stage_s[0] += t1 - t0; stage_s[1] += now_s() - t1; }
     if (info) {
       int ne = 0, np = 0;
       for (int i = 0; i < nc + ns; i++) { ne += corr[i].kind == ORC_KIND_EDGE; np += corr[i].kind == ORC_KIND_PLANE; }
@@ -740,6 +752,35 @@ static int match_scan2map_trees(const orc_point* map_corner, int mc, const orc_k
   }
   free(corr);
   return 0;
+}
+
+static int match_scan2map_trees(const orc_point* map_corner, int mc, const orc_kdtree* tc,
+                                const orc_point* map_surf, int ms, const orc_kdtree* ts,
+                                const orc_point* corner, int nc, const orc_point* surf, int ns,
+                                double pose[7], orc_match_info* info) {
+  return match_scan2map_trees_timed(map_corner, mc, tc, map_surf, ms, ts, corner, nc, surf, ns, pose, info, NULL);
+}
+
+/* Single-threaded batch with the reference's stage clocks: stage_seconds = {build tree (:73), Data association (:248),
+ * Solver time (:264)} summed over the scans; the kd-trees are rebuilt for every registration like the reference does. */
+void orc_match_scan2map_batch_timed(const orc_point* map_corner, int mc, const orc_point* map_surf, int ms,
+                                    int n_scans, const orc_point* corner, const int* corner_off,
+                                    const orc_point* surf, const int* surf_off,
+                                    double* poses, int* status, double stage_seconds[3]) {
+  stage_seconds[0] = stage_seconds[1] = stage_seconds[2] = 0.0;
+  if (mc < 5 || ms < 5) { for (int b = 0; b < n_scans; b++) if (status) status[b] = 2; return; }
+  for (int b = 0; b < n_scans; b++) {
+    const double t0 = now_s();
+    orc_kdtree* tc = orc_kdtree_build(map_corner, mc);
+    orc_kdtree* ts = orc_kdtree_build(map_surf, ms);
+    stage_seconds[0] += now_s() - t0;
+    int rc = match_scan2map_trees_timed(map_corner, mc, tc, map_surf, ms, ts,
+                                        corner + corner_off[b], corner_off[b + 1] - corner_off[b],
+                                        surf + surf_off[b], surf_off[b + 1] - surf_off[b],
+                                        poses + 7 * b, NULL, stage_seconds + 1);
+    if (status) status[b] = rc;
+    orc_kdtree_free(tc); orc_kdtree_free(ts);
+  }
 }
 
 int orc_match_scan2map(const orc_point* map_corner, int mc, const orc_point* map_surf, int ms,

@@ -230,6 +230,21 @@ def match_scan2map_batch(map_corner, map_surf, corner, corner_off, surf, surf_of
     return poses, status
 
 
+def match_scan2map_batch_timed(map_corner, map_surf, corner, corner_off, surf, surf_off, poses):
+    """Single-threaded batch with the reference's LOG_STEP_TIME stages: returns (poses, status,
+    {"build tree", "Data association", "Solver time"} seconds summed over the scans)."""
+    mc, ms, c, s = (as_points(a) for a in (map_corner, map_surf, corner, surf))
+    co = np.ascontiguousarray(corner_off, dtype=np.int32)
+    so = np.ascontiguousarray(surf_off, dtype=np.int32)
+    poses = np.array(poses, dtype=np.float64).reshape(-1, 7).copy()
+    B = len(poses)
+    status = np.zeros(B, np.int32)
+    st = np.zeros(3, np.float64)
+    lib().orc_match_scan2map_batch_timed(_p(mc), C.c_int(len(mc)), _p(ms), C.c_int(len(ms)), C.c_int(B), _p(c), _p(co),
+                                         _p(s), _p(so), _p(poses), _p(status), _p(st))
+    return poses, status, {"build tree": float(st[0]), "Data association": float(st[1]), "Solver time": float(st[2])}
+
+
 def match_scan2map_deskew(map_corner, map_surf, corner, surf, corner_dq, corner_dp, surf_dq, surf_dp,
                           velocity, gravity, pose):
     mc, ms, c, s = (as_points(a) for a in (map_corner, map_surf, corner, surf))

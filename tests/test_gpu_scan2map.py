@@ -291,3 +291,24 @@ def test_solver_corner_cases_follow_the_oracle(gpu, oracle, case):
         assert et < 0.05 and er < 0.01
     if case == "at_optimum":
         assert np.array_equal(pose_g, guess) or synth.pose_error(pose_g, guess)[0] < 1e-9
+
+
+@pytest.mark.gpu
+def test_candidate_counter_mode_counts_and_keeps_results(gpu):
+    """msfl_set_timing(h, 3): the counting 5-NN instantiation returns the same poses and a plausible count."""
+    import bench
+    inp = bench.build_inputs(8, 20000, 0)
+    h = gpu
+    h.set_map(inp["map_corner"], inp["map_surf"])
+    args = (inp["corner"], inp["corner_off"], inp["surf"], inp["surf_off"])
+    p0, s0, _ = h.match_scan2map_batch(*args, inp["guesses"].copy())
+    h.set_timing(3)
+    h.get_timing(reset=True)
+    p1, s1, _ = h.match_scan2map_batch(*args, inp["guesses"].copy())
+    t = h.get_timing(reset=True)
+    h.set_timing(0)
+    assert np.array_equal(p0, p1) and np.array_equal(s0, s1)
+    n_query = 2 * (len(inp["corner"]) + len(inp["surf"]))                # two outer iterations
+    assert t.launches_assoc == 2
+    assert 5 * n_query * 0.5 < t.knn_candidates < 2000 * n_query       # at least ~5 per accepted query, far below the map size
+    assert h.get_timing(reset=False).knn_candidates == 0                 # reset

@@ -325,3 +325,16 @@ def test_voxel_grid_matches_numpy_centroids(oracle):
     # every output lies in a distinct voxel, ordered by voxel index
     ijk = np.floor(out[:, :3] / np.float32(0.4)).astype(int)
     assert len(np.unique(ijk, axis=0)) == len(out)
+
+
+def test_timed_batch_equals_plain_batch_and_reports_stages(oracle):
+    """orc_match_scan2map_batch_timed (bench.py's stage table) runs the same arithmetic as the plain batch."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    inp = bench.build_inputs(3, 20000, 0)
+    args = (inp["map_corner"], inp["map_surf"], inp["corner"], inp["corner_off"], inp["surf"], inp["surf_off"], inp["guesses"])
+    p0, s0 = oracle.match_scan2map_batch(*args, threads=1, rebuild_tree_per_scan=True)
+    p1, s1, st = oracle.match_scan2map_batch_timed(*args)
+    assert np.array_equal(p0, p1) and np.array_equal(s0, s1)
+    assert set(st) == {"build tree", "Data association", "Solver time"} and all(v > 0 for v in st.values())
