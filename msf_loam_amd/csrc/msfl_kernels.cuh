@@ -297,10 +297,18 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
     gxa[k] = ga * ga * cellx2; gxb[k] = gb * gb * cellx2;
   }
   const msfl_f2 qxy = {q.x, q.y};
-  // visit order of the 9 (dy,dz) rows: centre, 4 edge neighbours, 4 diagonal neighbours.
-  // Fully unrolled: offsets are compile-time constants.
-  constexpr int DYS[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
-  constexpr int DZS[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+  // Visit order of the 9 (dy, dz) rows, PER QUERY: centre, then the two side rows on the query's near sides (smaller
+  // gap first), the two far side rows, the near-near diagonal, the two mixed diagonals, the far-far diagonal.  Any
+  // order is exact (a row is only skipped on a lower bound); this one makes the 64 queries of a wavefront need the
+  // same loop POSITIONS: with a fixed (-y, +y, -z, +z) order each position ran for the ~19 lanes whose near side it
+  // happened to be and cost the longest of their ranges, now the first two positions carry nearly all of that work
+  // and the later ones are skipped by the whole wavefront; the 5th-best distance also tightens sooner.
+  const bool y_lo = gy0 <= gy2, z_lo = gz0 <= gz2;                 // near side: the smaller gap
+  const int sy = y_lo ? -1 : 1, sz = z_lo ? -1 : 1;
+  const float g_ny = y_lo ? gy0 : gy2, g_fy = y_lo ? gy2 : gy0;
+  const float g_nz = z_lo ? gz0 : gz2, g_fz = z_lo ? gz2 : gz0;
+  const bool ny_first = g_ny <= g_nz, fy_first = g_fy <= g_fz;
+  const bool e_first = g_ny * g_ny + g_fz * g_fz <= g_fy * g_fy + g_nz * g_nz;   // (near y, far z) before (far y, near z)
   // candidates of the cells [a, b] of a row: x-adjacent cells are contiguous in the sorted array
   auto scan = [&](int row, int a, int b) __attribute__((always_inline)) {
     const int s = cell_start[row + a], e = cell_start[row + b + 1];
@@ -320,10 +328,21 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
   };
 #pragma unroll
   for (int r = 0; r < 9; r++) {
-    const int y = cy + DYS[r], z = cz + DZS[r];
+    int dy, dz; float gy, gz;
+    if (r == 0) { dy = 0; dz = 0; gy = gy1; gz = gz1; }
+    else if (r == 1 || r == 2) {                                    // near side rows
+      const bool yrow = (r == 1) == ny_first;
+      dy = yrow ? sy : 0; dz = yrow ? 0 : sz; gy = yrow ? g_ny : gy1; gz = yrow ? gz1 : g_nz;
+    } else if (r == 3 || r == 4) {                                  // far side rows
+      const bool yrow = (r == 3) == fy_first;
+      dy = yrow ? -sy : 0; dz = yrow ? 0 : -sz; gy = yrow ? g_fy : gy1; gz = yrow ? gz1 : g_fz;
+    } else if (r == 5) { dy = sy; dz = sz; gy = g_ny; gz = g_nz; }
+    else if (r == 6 || r == 7) {                                    // mixed diagonals
+      const bool e = (r == 6) == e_first;                           // e: (near y, far z)
+      dy = e ? sy : -sy; dz = e ? -sz : sz; gy = e ? g_ny : g_fy; gz = e ? g_fz : g_nz;
+    } else { dy = -sy; dz = -sz; gy = g_fy; gz = g_fz; }
+    const int y = cy + dy, z = cz + dz;
     if (y < 0 || y >= g.dy || z < 0 || z >= g.dz) continue;
-    const float gy = DYS[r] < 0 ? gy0 : (DYS[r] == 0 ? gy1 : gy2);
-    const float gz = DZS[r] < 0 ? gz0 : (DZS[r] == 0 ? gz1 : gz2);
     const float row2 = (gy * gy + gz * gz) * cell2;
     const int row = (z * g.dy + y) * g.dx;
     const float d4 = top5_d4(t);
