@@ -688,6 +688,16 @@ struct PlaneCache {
   float epx[kEdges + 1], epy[kEdges + 1], epz[kEdges + 1];
 };
 
+// Accepted edge correspondences of a solve, in index order.  Only ~40 % of the corner features pass the line test,
+// and an edge row costs 2.7 plane rows: the first pass marks the accepted ones in a bit mask, wavefront 0 turns the
+// mask into a dense index list, and the later passes (4 of 5) walk the list, so their lanes are all busy.
+constexpr int kEdgeListMax = 1024;                 // edges beyond this index keep the checked walk
+struct EdgeList {
+  unsigned mask[kEdgeListMax / 32];
+  unsigned short idx[kEdgeListMax];
+  int n;
+};
+
 // FILL: first pass of a solve (records come from global memory and are copied into the cache);
 // later passes read the cached part from LDS.  A thread only ever re-reads entries it wrote itself
 // (same i -> thread mapping in every pass), so no barrier is needed around the cache.
@@ -708,7 +718,7 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
                                               const float4* __restrict__ surf, int ns,
                                               const double* __restrict__ pprime,   // may be null
                                               const double* __restrict__ rec,      // this scan's records
-                                              PlaneCache<BLOCK>& pc,
+                                              PlaneCache<BLOCK>& pc, EdgeList& el,
                                               double (&acc)[kAcc], int& n_edge, int& n_plane) {
 #pragma unroll
   for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
@@ -716,7 +726,12 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   const mat3 R = quat_to_matrix(T.q);
   LM_T(t_eval_begin);
   // edges: {C, N}, r = N x (R p + t - C)                                       lidar_factor.cc:12
-  for (int i = threadIdx.x; i < nc; i += BLOCK) {
+  // FILL: every edge, accepted ones marked; later passes: the dense list first, then the unlisted tail
+  const int n_listed = FILL ? 0 : el.n;
+  const int n_walk = FILL ? nc : n_listed + max(nc - kEdgeListMax, 0);
+  for (int k = threadIdx.x; k < n_walk; k += BLOCK) {
+    const bool listed = !FILL && k < n_listed;
+    const int i = FILL ? k : (listed ? (int)el.idx[k] : kEdgeListMax + (k - n_listed));
     d3 C, N, p;
     if (!FILL && pprime == nullptr && i < PlaneCache<BLOCK>::kEdges) {
       C = mk3(pc.ecx[i], pc.ecy[i], pc.ecz[i]); N = mk3(pc.enx[i], pc.eny[i], pc.enz[i]);
@@ -735,7 +750,8 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
         }
       }
     }
-    if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) continue;      // rejected correspondence
+    if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) continue;      // rejected correspondence (never a listed one)
+    if (FILL && i < kEdgeListMax) atomicOr(&el.mask[i >> 5], 1u << (i & 31));
     const d3 d = lm_rotate(T.q, p) + T.t - C;
     n_edge++;
     const d3 r = cross(N, d);
@@ -1038,8 +1054,11 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
                 int outer_it, SolverParams prm) {
   __shared__ LmShared<BLOCK> sh;
   __shared__ PlaneCache<BLOCK> s_cache;
+  __shared__ EdgeList s_edges;
   const int b = blockIdx.x;
   if (status[b] != 0) return;
+  if (threadIdx.x < kEdgeListMax / 32) s_edges.mask[threadIdx.x] = 0;
+  __syncthreads();
   const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
   const int ns = bv.surf_off[b + 1] - bv.surf_off[b];
   const float4* corner = bv.corner + bv.corner_off[b];
@@ -1055,13 +1074,25 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
     int ne, np;
     const pose7 T = load_pose(pose_g);
     LM_T(t0);
-    evaluate_pass<BLOCK, true>(T, prm.huber, corner, nc, surf, ns, pprime, rec, s_cache, acc, ne, np);
+    evaluate_pass<BLOCK, true>(T, prm.huber, corner, nc, surf, ns, pprime, rec, s_cache, s_edges, acc, ne, np);
     LM_T(t1);
     block_reduce<BLOCK>(sh, acc, ne, np);
     LM_T(t2);
     LM_ADD(0, t1 - t0); LM_ADD(1, t2 - t1); LM_ADD(4, 1);
   }
   LM_T(t_s0);
+  // mask -> index list (32 lanes of wavefront 0, one mask word each; ascending index order, so the list and with it the
+  // summation order of the later passes is a function of the records alone)
+  if (threadIdx.x < kEdgeListMax / 32) {
+    unsigned m = s_edges.mask[threadIdx.x];
+    const int c = __popc(m);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { const int v = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += v; }
+    int at = incl - c;
+    while (m) { const int bit = __ffs((int)m) - 1; s_edges.idx[at++] = (unsigned short)(32 * threadIdx.x + bit); m &= m - 1; }
+    if (threadIdx.x == kEdgeListMax / 32 - 1) s_edges.n = incl;
+  }
   if (threadIdx.x == 0) {
     const int n_edge = sh.cnt[0], n_plane = sh.cnt[1];
     int go = 1;
@@ -1103,7 +1134,7 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
     const pose7 T = load_pose(tr.cand);
     __syncthreads();                       // everyone has read go / cand before lane 0 may overwrite them
     LM_T(t0);
-    evaluate_pass<BLOCK, false>(T, prm.huber, corner, nc, surf, ns, pprime, rec, s_cache, acc, ne, np);
+    evaluate_pass<BLOCK, false>(T, prm.huber, corner, nc, surf, ns, pprime, rec, s_cache, s_edges, acc, ne, np);
     LM_T(t1);
     block_reduce<BLOCK>(sh, acc, ne, np);
     LM_T(t2);

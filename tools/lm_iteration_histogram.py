@@ -14,3 +14,7 @@ for it in range(2):
     iters = np.array([i.lm_iterations[it] for i in info]); succ = np.array([i.lm_successful[it] for i in info])
     out[f"outer{it}"] = {"iterations": np.bincount(iters, minlength=8).tolist(), "successful": np.bincount(succ, minlength=8).tolist()}
 print(json.dumps(out))
+ne = np.array([[i.n_edge[it] for i in info] for it in range(2)]); npl = np.array([[i.n_plane[it] for i in info] for it in range(2)])
+nc = np.diff(inp["corner_off"]); ns = np.diff(inp["surf_off"])
+print(json.dumps({"edges_accepted_fraction": (ne.sum(1) / nc.sum()).tolist(), "planes_accepted_fraction": (npl.sum(1) / ns.sum()).tolist(),
+                  "edges_per_scan": float(nc.mean()), "planes_per_scan": float(ns.mean())}))
