@@ -501,7 +501,13 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   int n_cand = 0;
   if (is_edge) { const GridDesc gc = *gcp; knn5_grid(gc, map_c, cs_c, q, max_sq_dist, t, n_cand); }
   else { const GridDesc gs = *gsp; knn5_grid(gs, map_s, cs_s, q, max_sq_dist, t, n_cand); }
-  if (COUNT) atomicAdd(n_candidates, (unsigned long long)n_cand);
+  if (COUNT) {                                                  // one atomic per wavefront: sum over the lanes still here
+    const unsigned long long act = __ballot(1);
+    unsigned long long m = act;
+    int tot = 0;
+    while (m) { const int l = __ffsll((long long)m) - 1; tot += __shfl(n_cand, l); m &= m - 1; }
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(n_candidates, (unsigned long long)tot);
+  }
   if ((unsigned int)t.k4 != 0xffffffffu && (double)top5_d4(t) < (double)max_sq_dist) {      // :128 / :198
     // original map index -> position in the sorted map array (the fit kernel then gathers directly);
     // done here because this kernel runs at 8 waves/SIMD and hides the extra dependent load
