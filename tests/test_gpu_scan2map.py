@@ -262,7 +262,7 @@ def _synthetic_corr(rng, n_plane, n_edge, normals=None, noise=0.0, truth=None):
     return corr, truth
 
 
-@pytest.mark.parametrize("case", ["generic", "at_optimum", "edges_only", "two_normals", "outliers"])
+@pytest.mark.parametrize("case", ["generic", "at_optimum", "edges_only", "two_normals", "outliers", "many_edges"])
 def test_solver_corner_cases_follow_the_oracle(gpu, oracle, case):
     """The trust-region logic outside the comfortable regime: already converged, only edges, a
     rank-deficient geometry (two plane normals: the LM damping carries the solve), gross outliers
@@ -272,12 +272,21 @@ def test_solver_corner_cases_follow_the_oracle(gpu, oracle, case):
               at_optimum=dict(n_plane=300, n_edge=30, noise=0.0),
               edges_only=dict(n_plane=0, n_edge=120, noise=0.01),
               two_normals=dict(n_plane=300, n_edge=0, noise=0.005, normals=[[0, 0, 1], [1, 0, 0]]),
-              outliers=dict(n_plane=400, n_edge=40, noise=0.01))[case]
+              outliers=dict(n_plane=400, n_edge=40, noise=0.01),
+              many_edges=dict(n_plane=500, n_edge=2600, noise=0.01))[case]
     corr, truth = _synthetic_corr(rng, **kw)
     if case == "outliers":
         corr["C"][::7] += rng.normal(scale=3.0, size=(len(corr[::7]), 3))
+    if case == "many_edges":
+        # more edges than the solver's dense edge list holds (1 024), 60 % of them rejected correspondences (kind 0,
+        # N = C = 0) on both sides of that limit: the listed part and the checked tail must add up to the oracle's sum
+        drop = rng.random(2600) < 0.6
+        idx = np.nonzero(drop)[0]
+        corr["kind"][idx] = 0
+        corr["N"][idx] = 0.0
+        corr["C"][idx] = 0.0
     guess = truth.copy() if case == "at_optimum" else synth.perturb_pose(truth, rng, 0.2, 2.0)
-    ne = int((corr["kind"] == 1).sum())
+    ne = kw["n_edge"]
     corner = np.concatenate([corr["p"][:ne], np.zeros((ne, 1))], 1).astype(np.float32)
     surf = np.concatenate([corr["p"][ne:], np.zeros((len(corr) - ne, 1))], 1).astype(np.float32)
     rec = np.concatenate([corr["C"], corr["N"]], 1)
@@ -286,7 +295,7 @@ def test_solver_corner_cases_follow_the_oracle(gpu, oracle, case):
     assert info.lm_iterations[0] == summ.iterations and info.lm_successful[0] == summ.successful_steps, case
     dt, dr = synth.pose_error(pose_g, pose_o)
     assert dt < 1e-6 and dr < 1e-6, (case, dt, dr)
-    if case in ("generic", "edges_only", "outliers"):
+    if case in ("generic", "edges_only", "outliers", "many_edges"):
         et, er = synth.pose_error(pose_g, truth)
         assert et < 0.05 and er < 0.01
     if case == "at_optimum":
