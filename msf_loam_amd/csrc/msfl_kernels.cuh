@@ -922,7 +922,7 @@ __device__ __noinline__ int tr_propose(TrState& tr, const SolverParams& prm) {
     if (tr.step_ok && tr.gmax <= prm.gtol) return 0;
     if (tr.radius < prm.radius_min) return 0;
     tr.iteration++;
-    // One 6x6 live at a time: A = S H S (+ LM damping), factorised in place.
+    // A = S H S (+ LM damping); its Cholesky factor goes to L, A itself stays readable for the model cost change.
     double A[6][6], gs[6], y[6], lm2[6];
     {
       int n = 7;
@@ -937,15 +937,16 @@ __device__ __noinline__ int tr_propose(TrState& tr, const SolverParams& prm) {
 #pragma unroll
       for (int i = 0; i < 6; i++) tr.diagonal[i] = fmin(fmax(A[i][i], prm.min_diag), prm.max_diag);
     }
+    double hs_diag[6];                     // undamped diagonal of S H S, for the model cost change below
 #pragma unroll
     for (int i = 0; i < 6; i++) {
       const double lm = sqrt(tr.diagonal[i] / tr.radius);
       lm2[i] = lm * lm;
+      hs_diag[i] = A[i][i];
       A[i][i] += lm2[i];
     }
-    // step^T Hs step = step^T A step - sum lm2 step^2 is evaluated BEFORE the in-place factorisation
-    // destroys A, which needs the step first: so solve on a copy-free path: factorise, solve, then
-    // rebuild the quadratic form from the packed system.
+    // factorise, solve, then step^T Hs step from the very values A was formed from (off-diagonal entries of A and the
+    // diagonal saved before damping): no second pass over the packed system in LDS
     double L[6][6];
     bool ok = true;
 #pragma unroll
@@ -985,10 +986,8 @@ __device__ __noinline__ int tr_propose(TrState& tr, const SolverParams& prm) {
         gts += gs[i] * step[i];
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-          // Hs[i][j] rebuilt from the packed system exactly as A was formed (before damping)
-          const int p = i < j ? i : j, q = i < j ? j : i;
-          const int idx = 7 + p * 6 - (p * (p - 1)) / 2 + (q - p);
-          shs += step[i] * (tr.sys[idx] * tr.scale[p] * tr.scale[q]) * step[j];
+          // Hs[i][j]: the value A was formed from (A itself off the diagonal, the saved entry on it)
+          shs += step[i] * (i == j ? hs_diag[i] : A[i][j]) * step[j];
         }
       }
       mcc = -gts - 0.5 * shs;

@@ -87,13 +87,13 @@ __device__ __forceinline__ quat quat_normalized(quat q) {
 __device__ __forceinline__ quat delta_q(d3 v) {
   const double theta = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
   const double half_theta = 0.5 * theta;
-  double imag;
-  const double real = cos(half_theta);
+  double imag, real, sn;
+  sincos(half_theta, &sn, &real);          // one argument reduction for both (same values as sin() and cos())
   if (theta < 1e-6) {
     const double t2 = theta * theta, t4 = t2 * t2;
     imag = 0.5 - (1 / 48.) * t2 + (1 / 3840.) * t4;
   } else {
-    imag = sin(half_theta) / theta;
+    imag = sn / theta;
   }
   quat q; q.x = imag * v.x; q.y = imag * v.y; q.z = imag * v.z; q.w = real;
   return q;
