@@ -849,7 +849,8 @@ __device__ __forceinline__ void block_reduce(LmShared<BLOCK>& sh, double (&acc)[
     for (int w = 0; w < BLOCK / 64; w++) s += sh.cnt_part[w][threadIdx.x - kAcc];
     sh.cnt[threadIdx.x - kAcc] = s;
   }
-  __syncthreads();
+  // no barrier here: the sums are written and then read (trust-region logic, lane 0) inside wavefront 0, in program
+  // order; every other reader comes after the barrier that ends the serial section
 }
 
 // 6x6 SPD solve by Cholesky, fully unrolled; A symmetric (full storage), returns false if not PD
@@ -1136,8 +1137,8 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
   while (sh.go) {
     double acc[kAcc];
     int ne, np;
-    const pose7 T = load_pose(tr.cand);
-    __syncthreads();                       // everyone has read go / cand before lane 0 may overwrite them
+    const pose7 T = load_pose(tr.cand);   // lane 0 overwrites go / cand only after the reduction's barrier, which every
+                                           // thread reaches after this read: no barrier of its own needed
     LM_T(t0);
     evaluate_pass<BLOCK, false>(T, prm.huber, corner, nc, surf, ns, pprime, rec, s_cache, s_edges, acc, ne, np);
     LM_T(t1);
