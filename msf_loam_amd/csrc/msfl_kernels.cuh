@@ -892,6 +892,17 @@ __device__ __forceinline__ bool chol_solve6(const double (&A)[6][6], const doubl
   return ok;
 }
 
+// The only use of the gradient max-norm is the test `gmax <= gradient_tolerance`.  Its translation components are
+// |x_i - fl(x_i - g_i)| >= |g_i| - |x_i - g_i| 2^-53 (1 + 2^-53): for |x_i| < 1e6 that can only be <= gtol when
+// |g_i| <= gtol + 2.3e-10, so a translation gradient component above 2 gtol + 1e-9 decides the test without the
+// manifold step (sincos, quaternion product, normalisation) that the exact value needs.  Returns a value > gtol then.
+__device__ __forceinline__ double gradient_max_norm(const pose7& x, const double* g);
+__device__ __forceinline__ double gradient_max_norm_for_test(const pose7& x, const double* g, double gtol) {
+  const double gt = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+  const double xt = fmax(fabs(x.t.x), fmax(fabs(x.t.y), fabs(x.t.z)));
+  if (gt > 2.0 * gtol + 1e-9 && xt < 1e6) return gt;
+  return gradient_max_norm(x, g);
+}
 __device__ __forceinline__ double gradient_max_norm(const pose7& x, const double* g) {
   const pose7 xp = pose_plus(x, mk3(-g[0], -g[1], -g[2]), mk3(-g[3], -g[4], -g[5]));
   double m = fabs(x.t.x - xp.t.x);
@@ -1029,7 +1040,7 @@ __device__ __noinline__ int tr_decide(TrState& tr, const double* red, const Solv
     const pose7 x = load_pose(tr.x);
     tr.x_norm = pose_norm(x);
     tr.cost = cand_cost;
-    tr.gmax = gradient_max_norm(x, tr.sys + 1);
+    tr.gmax = gradient_max_norm_for_test(x, tr.sys + 1, prm.gtol);
     const double t = 2.0 * rel - 1.0;
     tr.radius = fmin(tr.radius / fmax(1.0 / 3.0, 1.0 - t * t * t), prm.radius_max);
     tr.decrease_factor = 2.0;
@@ -1122,7 +1133,7 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
 #pragma unroll
       for (int i = 0; i < 6; i++) tr.scale[i] = 1.0 / (1.0 + sqrt(sh.red[dg[i]]));
       const pose7 x = load_pose(tr.x);
-      tr.gmax = gradient_max_norm(x, tr.sys + 1);
+      tr.gmax = gradient_max_norm_for_test(x, tr.sys + 1, prm.gtol);
       tr.x_norm = pose_norm(x);
       tr.radius = prm.radius0; tr.decrease_factor = 2.0; tr.model_cost_change = 0.0;
       tr.invalid = 0; tr.reuse_diagonal = 0; tr.step_ok = 1;
