@@ -26,7 +26,7 @@ namespace msfl {
 // `pointSearchSqDis[4] < 1.0` gate: exact-kNN-equivalent on every ACCEPTED query.
 // ---------------------------------------------------------------------------------------------
 #ifndef MSFL_GRID_XSUB
-#define MSFL_GRID_XSUB 2
+#define MSFL_GRID_XSUB 3
 #endif
 constexpr int kGridXSub = MSFL_GRID_XSUB;
 
