@@ -94,7 +94,10 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
   int first = 0x7fffffff, bad = 0;
   // four 64-point groups per iteration with their loads issued up front: one workgroup per CU keeps 16 wavefronts
   // there, and one 16-byte load per lane in flight is far from what HBM needs to stay busy
-  constexpr int kGroups = 4;
+#ifndef MSFL_PREP_GROUPS
+#define MSFL_PREP_GROUPS 4
+#endif
+  constexpr int kGroups = MSFL_PREP_GROUPS;
   for (int g0 = w0; g0 < w1; g0 += 64 * kGroups) {
     float4 pp[kGroups]; int rr[kGroups];
 #pragma unroll
