@@ -290,7 +290,7 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv, const double* d_poses, 
                     const DeskewView& dv, int n_rec, double* full = nullptr) {
   hipStream_t st = h->stream;
   int* nn = h->nn.as<int>();
-  const dim3 grid(div_up(n_rec, 256)), block(256);
+  const dim3 grid(div_up(n_rec, kAssocBlock)), block(kAssocBlock);
   {
     ScopedTimer timer(h, T_ASSOC);
     if (h->timing == 3) {

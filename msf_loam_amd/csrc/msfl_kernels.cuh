@@ -458,8 +458,12 @@ struct DeskewView {
 // K4a: transform + exact 5-NN.  Low register count (no f64 fits here) -> 8 waves/SIMD to hide the
 // latency of the scattered 16-byte candidate loads.  nn[5*g..] = positions in the sorted map (nearest first),
 // nn[5*g] = -1 when the feature is rejected by the `pointSearchSqDis[4] < 1.0` gate (:128 / :198).
+#ifndef MSFL_ASSOC_BLOCK
+#define MSFL_ASSOC_BLOCK 64
+#endif
+constexpr int kAssocBlock = MSFL_ASSOC_BLOCK;      // threads per workgroup of the 5-NN and fit kernels
 template <bool DESKEW, bool COUNT = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kAssocBlock)
 knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
                      const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
                      const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
@@ -526,7 +530,7 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
 #define MSFL_FIT_WAVES 1
 #endif
 template <bool DESKEW>
-__global__ void __launch_bounds__(256, MSFL_FIT_WAVES)
+__global__ void __launch_bounds__(kAssocBlock, MSFL_FIT_WAVES)
 fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
                     const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
                     double* __restrict__ rec, double* __restrict__ full) {
