@@ -328,6 +328,10 @@ constexpr int kOdomTabStride = kOdomMaxCells + 1;       // per-pair table of col
 #define MSFL_ODOM_LANES 16
 #endif
 constexpr int kOdomLanes = MSFL_ODOM_LANES;             // lanes cooperating on one plane query
+#ifndef MSFL_ODOM_BLOCK
+#define MSFL_ODOM_BLOCK 64
+#endif
+constexpr int kOdomBlock = MSFL_ODOM_BLOCK;             // threads per workgroup of the column-grid query kernel
 constexpr int kOdomMidLevel = 2;
 constexpr int kOdomMaxLevel = 6;                        // gap >= 6 m  >  sqrt(25): nothing outside can pass the 25 m^2 gate
 
@@ -481,7 +485,7 @@ __device__ __forceinline__ unsigned long long group_min_key(unsigned long long k
 // EDGE = false: flat queries against the less-flat cloud (:166-258); EDGE = true: sharp queries against the
 // less-sharp cloud (:81-163: second point only from rings (id, id + 2.5] above / [id - 2.5, id) below).
 template <int L, bool EDGE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kOdomBlock)
 assoc_scan2scan_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const double* __restrict__ poses,
                             const int* __restrict__ status, double* __restrict__ rec) {
   // XCD-aware block -> (pair, tile) mapping.  Workgroups are dealt round-robin to the 8 XCDs (block i -> XCD i % 8)
@@ -498,7 +502,7 @@ assoc_scan2scan_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const doubl
   const int n_sharp = bv.corner_off[b + 1] - bv.corner_off[b];
   const int n_flat = bv.surf_off[b + 1] - bv.surf_off[b];
   const int sl = threadIdx.x % L;
-  const int qf = tile * (256 / L) + threadIdx.x / L;
+  const int qf = tile * (kOdomBlock / L) + threadIdx.x / L;
   if (qf >= (EDGE ? n_sharp : n_flat)) return;
   constexpr int kOut = EDGE ? 6 : 4;
   double* out = rec + rec_base(bv, b) + (EDGE ? 6 * (size_t)qf : 6 * (size_t)n_sharp + 4 * (size_t)qf);
