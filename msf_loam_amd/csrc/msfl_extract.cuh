@@ -32,6 +32,11 @@ struct ExtractParams {
   int sectors, max_sharp, max_less_sharp, max_flat;
 };
 
+#ifndef MSFL_STREAM_BLOCK
+#define MSFL_STREAM_BLOCK 128
+#endif
+constexpr int kStreamBlock = MSFL_STREAM_BLOCK;   // threads per workgroup of the one-thread-per-element kernels (curvature, batched voxel filter)
+
 struct ExtractView {
   // inputs (per scan b: [off[b], off[b+1]) )
   const float4* in_pts; const uint16_t* in_ring; const int* off; int n_scans; int n_total;
