@@ -35,6 +35,10 @@ struct ExtractParams {
 #ifndef MSFL_STREAM_BLOCK
 #define MSFL_STREAM_BLOCK 128
 #endif
+#ifndef MSFL_EXTRACT_WAVES
+#define MSFL_EXTRACT_WAVES 4
+#endif
+constexpr int kExWaves = MSFL_EXTRACT_WAVES;       // independent wavefronts per workgroup of the sector sort / pick kernels
 constexpr int kStreamBlock = MSFL_STREAM_BLOCK;   // threads per workgroup of the one-thread-per-element kernels (curvature, batched voxel filter)
 
 struct ExtractView {
@@ -335,14 +339,14 @@ __device__ __forceinline__ void wave_bitonic_sort(KeyPtr keys, int P, int lane, 
 // One wavefront per (scan, ring, sector): sort the sector's (curvature, index) keys ascending and
 // leave them at sortbuf[2*(o+sp) ...] (cnt entries).  Splitting the sort from the (serial) pick gives
 // six times more wavefronts for the part that dominates the instruction count.
-__global__ void __launch_bounds__(256) extract_sort_kernel(ExtractView v, ExtractParams prm) {
-  __shared__ unsigned long long s_keys[4][kSortLds];
+__global__ void __launch_bounds__(64 * kExWaves) extract_sort_kernel(ExtractView v, ExtractParams prm) {
+  __shared__ unsigned long long s_keys[kExWaves][kSortLds];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // grid = (scans, unit groups): scans on the FAST block index.  Only the first few unit groups of a
   // scan have work (16 of 128 rings on a VLP-16); with groups on the fast index the busy workgroups
   // shared a residue mod 32 and the round-robin dispatcher packed them onto 32 of the 256 CUs.
   const int b = blockIdx.x;
-  const int unit = blockIdx.y * 4 + wave;                 // ring * sectors + sector
+  const int unit = blockIdx.y * kExWaves + wave;                 // ring * sectors + sector
   const int r = unit / prm.sectors, j = unit - r * prm.sectors;
   if (r >= kMaxRings || v.status[b] != 0) return;
   const int* tab = v.ring_tab + b * (kMaxRings + 1);
@@ -424,14 +428,14 @@ __device__ __forceinline__ void neighbour_span(const RingBits& gap, int q, int& 
   back = __clz((int)((b5 << 27) | (1u << 26)));      // leading zeros of the 5-bit field (0..5)
 }
 
-__global__ void __launch_bounds__(256) extract_pick_kernel(ExtractView v, ExtractParams prm) {
-  __shared__ unsigned long long s_keys[4][kSortLds];
-  __shared__ unsigned int s_picked[4][kRingCapacity / 32 + 2];
-  __shared__ unsigned int s_corner[4][kRingCapacity / 32 + 2];
-  __shared__ unsigned int s_gap[4][kRingCapacity / 32 + 2];
+__global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView v, ExtractParams prm) {
+  __shared__ unsigned long long s_keys[kExWaves][kSortLds];
+  __shared__ unsigned int s_picked[kExWaves][kRingCapacity / 32 + 2];
+  __shared__ unsigned int s_corner[kExWaves][kRingCapacity / 32 + 2];
+  __shared__ unsigned int s_gap[kExWaves][kRingCapacity / 32 + 2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x;                               // scans on the fast block index (see extract_sort_kernel)
-  const int r = blockIdx.y * 4 + wave;
+  const int r = blockIdx.y * kExWaves + wave;
   if (r >= kMaxRings) return;
   int* cnt_out = v.ring_cnt + ((size_t)b * kMaxRings + r) * 4;
   const int* tab = v.ring_tab + b * (kMaxRings + 1);
