@@ -665,7 +665,7 @@ __device__ __forceinline__ void huber_rho_scalar(double a, double resid, double&
 // that consecutive lanes hit consecutive banks).  A solve re-reads every record in each of its ~4-7
 // evaluation passes: what fits here is fetched from HBM once per solve instead of once per pass.
 #ifndef MSFL_LM_BLOCK
-#define MSFL_LM_BLOCK 256
+#define MSFL_LM_BLOCK 128
 #endif
 constexpr int kLmBlock = MSFL_LM_BLOCK;                        // threads per scan in the scan-to-map LM solve
 #ifndef MSFL_ODOM_LM_BLOCK
