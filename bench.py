@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+ASSOC_KERNEL_PREFIX = "knn5_scan2map_kernel"   # the dominant kernel (rocprofv3 name prefix; template arguments follow)
 
 
 def build_inputs(B, map_points, seed_offset, extractor=None):
@@ -99,7 +100,57 @@ def cpu_baseline(inp, sample, threads):
     t0 = time.perf_counter()
     poses, status = orc.match_scan2map_batch(*args, threads=threads, rebuild_tree_per_scan=True)
     t1 = time.perf_counter()
-    return dict(value=n / (t1 - t0), single_thread_value=single, n=n, n_single=n1, poses=poses, stages_ms=stages_ms)
+    # like-for-like with the GPU step, which indexes the map ONCE per batch: one kd-tree for the whole sample
+    t2 = time.perf_counter()
+    orc.match_scan2map_batch(*args, threads=threads, rebuild_tree_per_scan=False)
+    t3 = time.perf_counter()
+    return dict(value=n / (t1 - t0), value_one_tree=n / (t3 - t2), single_thread_value=single, n=n, n_single=n1, poses=poses,
+                stages_ms=stages_ms)
+
+
+def self_launch(n):
+    """Re-run this command under torch.distributed.run with n local ranks; returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the kernel whose name starts with `kernel_prefix`, from the committed rocprofv3
+    --pmc profile of this command (PMC counters cannot be sampled from inside the process).  A missing file
+    means "no profile yet" (None); a profile WITHOUT the kernel is an error, never a silent null."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        pt = json.load(f)
+    # `<..., true>` is the candidate-counting instantiation of the 5-NN kernel (one extra, untimed step): not the product launch
+    hits = [k for k in pt["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>")]
+    if not hits:
+        raise KeyError("profiles/pmc_traffic.json has no kernel starting with %r (keys: %s)" % (kernel_prefix, sorted(pt["kernels"])))
+    return sum(pt["kernels"][k]["hbm_bytes_per_launch"] for k in hits), pt["source"]
+
+
+def host_buffer_rate(h, inp, B, reps=5):
+    """PCIe-inclusive rate (batch wall time incl. H2D of the features, excl. the one-time map
+    upload / index): features, guesses and results in pinned host memory, the map resident and indexed."""
+    import torch
+    c, s, g = (torch.from_numpy(inp[k]).pin_memory().numpy() for k in ("corner", "surf", "guesses"))
+    co, so = inp["corner_off"], inp["surf_off"]
+    for _ in range(2):
+        h.match_scan2map_batch(c, co, s, so, g)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        h.match_scan2map_batch(c, co, s, so, g)
+    dt = (time.perf_counter() - t0) / reps
+    return B / dt, 1e3 * dt, int(c.nbytes + s.nbytes + g.nbytes)
 
 
 def main():
@@ -112,6 +163,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=128, help="scans timed on the CPU oracle (0 disables)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: leave the per-kernel HIP events off during the timed steps (roofline.achieved is then 0)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive leg (value_incl_h2d)")
     ap.add_argument("--features", choices=["product", "direct"], default="product",
                     help="product: features from the GPU extraction + voxel kernels; direct: from ray-cast hit kinds")
     args = ap.parse_args()
@@ -122,9 +174,12 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, rendezvous on
+        # 127.0.0.1) and hand their output through; rank 0 of the child job prints the one JSON line
+        raise SystemExit(self_launch(args.gpus))
     if args.gpus != world_size:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_size))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # test hook (1-GPU boxes): MSFL_BENCH_SHARED_GPU=1 puts every rank on cuda:0 and swaps RCCL for gloo, so that the
@@ -217,10 +272,15 @@ def main():
     knn_candidates = h.get_timing(reset=True).knn_candidates
     h.set_timing(0)
     gc.enable()
+    rank_ms = [1e3 * elapsed / args.steps]
+    rccl_ranks = 1
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if not shared_gpu else "cpu")
+        every = [torch.zeros_like(t) for _ in range(world_size)]
+        dist.all_gather(every, t)
+        rank_ms = [1e3 * float(e.item()) / args.steps for e in every]
+        elapsed = max(float(e.item()) for e in every)          # MAX over ranks
+        rccl_ranks = dist.get_world_size()
 
     poses_gpu = d_poses.cpu().numpy()
     status_gpu = d_status.cpu().numpy()
@@ -240,20 +300,21 @@ def main():
         achieved = alg_bytes_assoc / (assoc_ms * 1e-3) / 1e9 if assoc_ms > 0 else 0.0
         # HBM traffic of the dominant kernel: PMC counters cannot be sampled from inside this process, so
         # the figure comes from the committed rocprofv3 --pmc profile of this same command
-        # (profiles/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch), or null.
-        traffic, traffic_src = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pt = json.load(f)
-            if B == 1024 and args.map_points == 200000:
-                traffic = pt["kernels"]["knn5_scan2map_kernel<false>"]["hbm_bytes_per_launch"]
-                traffic_src = pt["source"]
-        except Exception:
-            pass
+        # (profiles/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch); null only when the
+        # workload is not the profiled one.
+        traffic, traffic_src = None, "not the profiled workload (B=1024, 200k-pt map)"
+        if B == 1024 and args.map_points == 200000:
+            traffic, traffic_src = pmc_traffic(ASSOC_KERNEL_PREFIX)
+        # whole step: every outer iteration reads each feature and its five neighbours once, the map once per batch,
+        # one pose in and out per scan; kernels in between communicate through HBM, which is not
+        # algorithmic
+        alg_bytes_step = n_outer * F_total * 96 + (n_mc + n_ms) * 16 + B * 112
+        step_s = elapsed / args.steps
         out = {
             "metric": "scan-to-map registrations/s", "value": value, "unit": "registrations/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "rccl_ranks": rccl_ranks, "ms_per_step_per_rank": rank_ms,
             "vs_baseline": None, "dtype": "f64 (f32 kNN distances)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: batch of %d VLP-16 scans (16x1800) vs %d-pt local map, "
                                    "2 outer x [exact 5-NN + line/plane fit, LM<=6 + Huber 0.1]" % (B, n_mc + n_ms),
@@ -262,7 +323,9 @@ def main():
                        "index_rebuilt_per_step": True, "parallelism": "scan-sharded x%d, map replicated" % world_size},
             "roofline": {"bound": "hbm", "kernel": "knn5_scan2map_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes_assoc, "avg_launch_ms": assoc_ms},
+                         "algorithmic_bytes_per_launch": alg_bytes_assoc, "avg_launch_ms": assoc_ms,
+                         "step": {"algorithmic_bytes_per_step": alg_bytes_step, "achieved": alg_bytes_step / step_s / 1e9,
+                                  "unit": "GB/s", "frac": alg_bytes_step / step_s / 1e9 / HBM_PEAK_GBS}},
             "kernels_ms": {"assoc": assoc_ms, "fit": timing_all.ms_fit / max(timing_all.launches_fit, 1), "solve": solve_ms,
                            "index_build": index_ms,
                            "note": "assoc: HIP events inside the timed region; fit / solve / index_build: 3 extra steps after it",
@@ -275,6 +338,12 @@ def main():
             "prep_s": t_prep,
             "n_failed": int((status_gpu != 0).sum()),
         }
+        out["value_incl_h2d"] = None               # N=1 only: the host-buffer call is a separate, untimed-for-`value` leg
+        if world_size == 1 and not args.no_h2d:
+            v, ms, nbytes = host_buffer_rate(h, inp, B)
+            out["value_incl_h2d"] = {"value": v, "unit": "registrations/s", "ms_per_batch": ms, "host_bytes_in": nbytes,
+                                     "note": "same batch with features, guesses and results in pinned host memory (PCIe "
+                                             "staging inside the call), map resident and indexed; never `value`"}
         out["cpu_baseline"] = None                 # timed on rank 0 at N=1 only (the other ranks would idle behind it)
         if args.cpu_sample > 0 and world_size == 1:
             cores = os.cpu_count() or 1
@@ -282,6 +351,10 @@ def main():
             dts, drs = zip(*[synth.pose_error(poses_gpu[i], cb["poses"][i]) for i in range(cb["n"])])
             out["cpu_baseline"] = {"value": cb["value"], "unit": "registrations/s", "cores": cores, "kind": "port",
                                    "single_thread_value": cb["single_thread_value"],
+                                   "value_one_tree_per_batch": cb["value_one_tree"],
+                                   "like_for_like": "`value` rebuilds the kd-tree for every registration (the reference's cost "
+                                                    "structure, mapping_scan_matcher.cc:66-73); `value_one_tree_per_batch` builds it "
+                                                    "once for the sample, which is what the GPU step (one index build per batch) does",
                                    "sample": "%d of the %d scans of rank 0, oracle/msfl_oracle.c with per-registration "
                                              "kd-tree rebuild, OpenMP over scans on %d threads (single-thread figure on %d scans)"
                                              % (cb["n"], B, cores, cb["n_single"])}

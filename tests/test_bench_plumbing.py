@@ -1,0 +1,36 @@
+"""bench.py plumbing that needs no GPU: the PMC traffic lookup must find the dominant kernel in the committed
+profile (a silent null was VERDICT r01 item 7), and `python bench.py --gpus N` must start N ranks by itself."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_pmc_traffic_finds_the_dominant_kernel():
+    import bench
+    traffic, src = bench.pmc_traffic(bench.ASSOC_KERNEL_PREFIX)
+    assert traffic is not None and traffic > 0 and src
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        keys = list(json.load(f)["kernels"])
+    assert any(k.startswith(bench.ASSOC_KERNEL_PREFIX) for k in keys)
+
+
+def test_pmc_traffic_fails_loudly_on_a_missing_kernel():
+    import bench
+    import pytest
+    with pytest.raises(KeyError):
+        bench.pmc_traffic("no_such_kernel")
+
+
+def test_plain_gpus_2_launches_two_ranks():
+    """No GPU here: every rank must get as far as bench.py's own "needs a GPU" exit, i.e. the plain
+    `python bench.py --gpus 2` form launched ranks instead of refusing to run."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+    err = out.stderr + out.stdout
+    assert "launch with torch.distributed.run" not in err
+    assert err.count("bench.py needs a GPU") >= 2, err[-2000:]
+    assert out.returncode != 0

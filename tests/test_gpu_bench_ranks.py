@@ -11,11 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_two_ranks_print_one_whole_job_line():
+@pytest.mark.parametrize("launched", [True, False], ids=["torch.distributed.run", "plain python (self-launch)"])
+def test_two_ranks_print_one_whole_job_line(launched):
     env = dict(os.environ, MSFL_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scans", "64",
-           "--cpu-sample", "0"]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29541"] if launched else [sys.executable]
+    cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scans", "64", "--cpu-sample", "0"]
+    env.pop("RANK", None)
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -26,4 +28,6 @@ def test_two_ranks_print_one_whole_job_line():
     # whole-job value: both ranks' registrations over the max-over-ranks time
     assert abs(d["value"] - 2 * 64 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert d["cpu_baseline"] is None
+    assert d["rccl_ranks"] == 2 and len(d["ms_per_step_per_rank"]) == 2
+    assert abs(max(d["ms_per_step_per_rank"]) - d["ms_per_step"]) < 1e-9
     assert d["n_failed"] == 0

@@ -229,3 +229,32 @@ def test_randomised_pairs_three_paths_agree(gpu, oracle, seed):
     guesses = np.stack([guess] * 45)
     poses, status, _ = gpu.match_scan2scan_batch(_batch_sets(pairs), guesses)
     assert np.all(status == s) and all(np.array_equal(poses[b], pose_g) for b in (0, 17, 44))
+
+
+def test_large_gate_keeps_the_batch_path_exact(oracle):
+    """the column-grid walk is exhaustive only for gates below 36 m^2.  With
+    odom_distance_sq_threshold = 64 the batch call must leave the grid and still reproduce the
+    single-pair (exhaustive wave kernel) results bit for bit, with guesses 6-7.5 m off so that every
+    accepted correspondence lies beyond the grid's 13 x 13 column reach."""
+    prm = capi.default_params()
+    prm.odom_distance_sq_threshold = 64.0
+    h = capi.Handle(0, prm)
+    try:
+        ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+        base = [_clouds(*_pair(oracle, i)) for i in range(3)]
+        pairs = [base[i % 3] for i in range(45)]
+        guesses = np.stack([ident] * 45)
+        guesses[:, 0] = np.linspace(6.0, 7.5, 45)
+        sets = _batch_sets(pairs)
+        assert 45 * max(len(p[4]) + len(p[5]) for p in pairs) > 16384          # the throughput path
+        poses, status, info = h.match_scan2scan_batch(sets, guesses, want_info=True)
+        n_corr = 0
+        for b in (0, 1, 2, 17, 31, 44):
+            s, p, i1 = h.match_scan2scan(*pairs[b], guesses[b])
+            assert s == status[b], b
+            assert np.array_equal(p, poses[b]), b
+            assert i1.n_plane[0] == info[b].n_plane[0] and i1.n_edge[0] == info[b].n_edge[0], b
+            n_corr += i1.n_plane[0] + i1.n_edge[0]
+        assert n_corr > 0                                                       # the wide gate really found something
+    finally:
+        h.close()
