@@ -611,51 +611,57 @@ struct DevMatchInfo {   // mirrors msfl_match_info
   double initial_cost[2], final_cost[2];
 };
 
+#ifndef MSFL_LM_EXP
+#define MSFL_LM_EXP 0     // timing experiments only, wrong results (2: streamed plane records loaded but not evaluated, 3: evaluated without loads)
+#endif
 constexpr int kAcc = 28;   // cost + g[6] + H upper[21]
 
-// row of the (robustified) Jacobian: a = d r/d t (3); rotation part b = -(R skew(p))^T a
-// = p x (R^T a)  (lidar_factor.cc:19,39 in closed form); residual ra; sc = sqrt(rho')
-__device__ __forceinline__ void acc_row(double (&acc)[kAcc], const mat3& R, d3 p, d3 a, double ra, double sc) {
-#pragma clang fp contract(fast)   // accumulation only: fused multiply-adds, parity is a 1e-4 bar
-  const d3 l = mk3(R.m[0] * a.x + R.m[3] * a.y + R.m[6] * a.z,
-                   R.m[1] * a.x + R.m[4] * a.y + R.m[7] * a.z,
-                   R.m[2] * a.x + R.m[5] * a.y + R.m[8] * a.z);
-  const d3 b = cross(p, l);
-  const double j[6] = {sc * a.x, sc * a.y, sc * a.z, sc * b.x, sc * b.y, sc * b.z};
-  const double r = sc * ra;
+// ---- robustified normal equations, one residual row at a time ----------------------------------------------
+// Ceres scales residual and Jacobian of a block by sqrt(rho') (Corrector with rho'' <= 0) and then forms
+// J^T J / J^T r.  The products only ever contain sqrt(rho')^2, so the accumulation below weights the row
+// with w = rho' directly: no square root per record, results equal up to the rounding of sqrt(w)^2 vs w.
+// j[0..2] = d r/d t, j[3..5] = d r/d theta (tangent space, lidar_factor.cc:19,39 in closed form).
+__device__ __forceinline__ void acc_row_w(double (&acc)[kAcc], const double (&j)[6], double r, double w) {
+  double jw[6];
 #pragma unroll
-  for (int k = 0; k < 6; k++) acc[1 + k] += j[k] * r;
+  for (int k = 0; k < 6; k++) jw[k] = w * j[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc[1 + k] = __builtin_fma(jw[k], r, acc[1 + k]);
   int n = 7;
 #pragma unroll
   for (int p2 = 0; p2 < 6; p2++)
 #pragma unroll
-    for (int q = p2; q < 6; q++) acc[n++] += j[p2] * j[q];
+    for (int q = p2; q < 6; q++) { acc[n] = __builtin_fma(jw[p2], j[q], acc[n]); n++; }
 }
 
-__device__ __forceinline__ void huber_rho(double a, double s, double& rho0, double& rho1) {
-  const double b = a * a;
-  if (s > b) {
-    const double r = sqrt(s);
-    rho0 = 2.0 * a * r - b;
-    rho1 = fmax(2.2250738585072014e-308, a / r);
-  } else {
-    rho0 = s; rho1 = 1.0;
-  }
+// 1 / x for x in a benign range (no scaling / fix-up steps of the IEEE division sequence): v_rcp_f64 + two Newton
+// steps, within an ulp or two of the correctly rounded quotient
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+// 1 / sqrt(x), x > 0 and far from the denormal range: v_rsq_f64 + two Newton steps
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  double e = __builtin_fma(-hx * y, y, 0.5);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-hx * y, y, 0.5);
+  return __builtin_fma(y, e, y);
 }
 
-// Plane rows: the robustifier's argument is s = r * r of ONE residual, and in binary floating point sqrt(fl(r * r)) == |r|
-// whenever r * r neither underflows nor overflows (checked on 2e8 random and full-mantissa doubles): inside the
-// outlier branch (s > delta^2) the first of the corrector's two square roots is therefore |r|, bit for bit.
-__device__ __forceinline__ void huber_rho_scalar(double a, double resid, double& rho0, double& rho1) {
+// HuberLoss(a) on s = |r|^2 given |r|: rho0 = rho(s), w = rho'(s) (Ceres loss_function.cc; the Corrector's
+// max(DBL_MIN, .) guard is kept)
+__device__ __forceinline__ void huber_weight(double a, double s, double abs_r, double& rho0, double& w) {
   const double b = a * a;
-  const double s = resid * resid;
   if (s > b) {
-    double r = fabs(resid);
-    if (!(s <= 1.7976931348623157e308)) r = sqrt(s);      // overflowed square: keep the literal form
-    rho0 = 2.0 * a * r - b;
-    rho1 = fmax(2.2250738585072014e-308, a / r);
+    rho0 = 2.0 * a * abs_r - b;
+    w = fmax(2.2250738585072014e-308, a * fast_rcp(abs_r));
   } else {
-    rho0 = s; rho1 = 1.0;
+    rho0 = s; w = 1.0;
   }
 }
 
@@ -762,45 +768,84 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
     }
     if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) continue;      // rejected correspondence (never a listed one)
     if (FILL && i < kEdgeListMax) atomicOr(&el.mask[i >> 5], 1u << (i & 31));
-    const d3 d = lm_rotate(T.q, p) + T.t - C;
     n_edge++;
-    const d3 r = cross(N, d);
-    const double s = r.x * r.x + r.y * r.y + r.z * r.z;
-    double rho0, rho1; huber_rho(huber, s, rho0, rho1);
+    // d = R p + t - C through the rotation matrix (the quaternion sandwich costs three times the instructions; the two agree
+    // to rounding), r = N x d
+    const d3 d = mk3(__builtin_fma(R.m[0], p.x, __builtin_fma(R.m[1], p.y, R.m[2] * p.z)) + (T.t.x - C.x),
+                     __builtin_fma(R.m[3], p.x, __builtin_fma(R.m[4], p.y, R.m[5] * p.z)) + (T.t.y - C.y),
+                     __builtin_fma(R.m[6], p.x, __builtin_fma(R.m[7], p.y, R.m[8] * p.z)) + (T.t.z - C.z));
+    const d3 r = mk3(__builtin_fma(N.y, d.z, -(N.z * d.y)), __builtin_fma(N.z, d.x, -(N.x * d.z)), __builtin_fma(N.x, d.y, -(N.y * d.x)));
+    const double s = __builtin_fma(r.x, r.x, __builtin_fma(r.y, r.y, r.z * r.z));
+    double rho0 = s, w = 1.0;
+    if (s > huber * huber) {                                     // rho acts on the 3-vector norm of the block
+      const double inv = fast_rsqrt(s);
+      rho0 = 2.0 * huber * (s * inv) - huber * huber;
+      w = fmax(2.2250738585072014e-308, huber * inv);
+    }
     acc[0] += 0.5 * rho0;
-    const double sc = sqrt(rho1);
-    acc_row(acc, R, p, mk3(0.0, -N.z, N.y), r.x, sc);          // rows of skew(N), :18-19
-    acc_row(acc, R, p, mk3(N.z, 0.0, -N.x), r.y, sc);
-    acc_row(acc, R, p, mk3(-N.y, N.x, 0.0), r.z, sc);
+    // rows of skew(N) (:18-19): a0 = (0, -Nz, Ny), a1 = (Nz, 0, -Nx), a2 = (-Ny, Nx, 0); rotation part p x (R^T a_k),
+    // R^T a_k from two rows of R each
+    const d3 l0 = mk3(__builtin_fma(N.y, R.m[6], -(N.z * R.m[3])), __builtin_fma(N.y, R.m[7], -(N.z * R.m[4])), __builtin_fma(N.y, R.m[8], -(N.z * R.m[5])));
+    const d3 l1 = mk3(__builtin_fma(N.z, R.m[0], -(N.x * R.m[6])), __builtin_fma(N.z, R.m[1], -(N.x * R.m[7])), __builtin_fma(N.z, R.m[2], -(N.x * R.m[8])));
+    const d3 l2 = mk3(__builtin_fma(N.x, R.m[3], -(N.y * R.m[0])), __builtin_fma(N.x, R.m[4], -(N.y * R.m[1])), __builtin_fma(N.x, R.m[5], -(N.y * R.m[2])));
+    const d3 b0 = cross(p, l0), b1 = cross(p, l1), b2 = cross(p, l2);
+    const double j0[6] = {0.0, -N.z, N.y, b0.x, b0.y, b0.z};
+    const double j1[6] = {N.z, 0.0, -N.x, b1.x, b1.y, b1.z};
+    const double j2[6] = {-N.y, N.x, 0.0, b2.x, b2.y, b2.z};
+    acc_row_w(acc, j0, r.x, w);
+    acc_row_w(acc, j1, r.y, w);
+    acc_row_w(acc, j2, r.z, w);
   }
   LM_T(t_edges_done);
   // planes: {N, N.C}, r = N.(R p + t) - N.C                                    lidar_factor.cc:32
   const double* recp = rec + 6 * (size_t)nc;
   const bool use_cache = (pprime == nullptr);       // deskew keeps f64 points in global memory
-  for (int i = threadIdx.x; i < ns; i += BLOCK) {
-    d3 N, p; double d0;
-    if (!FILL && use_cache && i < PlaneCache<BLOCK>::kPlanes) {
-      N = mk3(pc.nx[i], pc.ny[i], pc.nz[i]); d0 = pc.d0[i];
-      p = mk3((double)pc.px[i], (double)pc.py[i], (double)pc.pz[i]);
-    } else {
-      const double* r4 = recp + 4 * (size_t)i;
-      N = mk3(r4[0], r4[1], r4[2]); d0 = r4[3];
-      if (pprime) { const size_t k = (size_t)(nc + i); p = mk3(pprime[3 * k], pprime[3 * k + 1], pprime[3 * k + 2]); }
-      else {
-        const float4 f = surf[i];                              // curr_point: untransformed (:221)
-        p = mk3((double)f.x, (double)f.y, (double)f.z);
-        if (FILL && i < PlaneCache<BLOCK>::kPlanes) {
-          pc.nx[i] = N.x; pc.ny[i] = N.y; pc.nz[i] = N.z; pc.d0[i] = d0;
-          pc.px[i] = f.x; pc.py[i] = f.y; pc.pz[i] = f.z;
-        }
+  auto plane_row = [&](d3 N, double d0, d3 p) __attribute__((always_inline)) {
+    if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) return;        // rejected correspondence
+    n_plane++;
+    // r = N.(R p + t) - d0 = (R^T N).p + (N.t - d0): the vector l = R^T N is what the Jacobian's rotation part
+    // p x (R^T N) needs anyway (:38-39), so the residual costs six fused multiply-adds on top of it
+    const d3 l = mk3(__builtin_fma(R.m[0], N.x, __builtin_fma(R.m[3], N.y, R.m[6] * N.z)),
+                     __builtin_fma(R.m[1], N.x, __builtin_fma(R.m[4], N.y, R.m[7] * N.z)),
+                     __builtin_fma(R.m[2], N.x, __builtin_fma(R.m[5], N.y, R.m[8] * N.z)));
+    const double nt = __builtin_fma(N.x, T.t.x, __builtin_fma(N.y, T.t.y, __builtin_fma(N.z, T.t.z, -d0)));
+    const double r = __builtin_fma(l.x, p.x, __builtin_fma(l.y, p.y, __builtin_fma(l.z, p.z, nt)));
+    const d3 b = cross(p, l);
+    double rho0, w; huber_weight(huber, r * r, fabs(r), rho0, w);
+    acc[0] += 0.5 * rho0;
+    const double j[6] = {N.x, N.y, N.z, b.x, b.y, b.z};
+    acc_row_w(acc, j, r, w);
+  };
+  // (a) the LDS-resident head of the plane list (later passes; a thread reads back what it wrote itself)
+  int i = threadIdx.x;
+  if (!FILL && use_cache) {
+    for (; i < min(ns, PlaneCache<BLOCK>::kPlanes); i += BLOCK)
+      plane_row(mk3(pc.nx[i], pc.ny[i], pc.nz[i]), pc.d0[i], mk3((double)pc.px[i], (double)pc.py[i], (double)pc.pz[i]));
+  }
+  // (b) the streamed rest (everything in the FILL pass).  Software-pipelining these loads two iterations ahead was
+  // measured SLOWER (0.279 vs 0.229 ms per solve): the pass is not waiting for its record loads.
+  for (; i < ns; i += BLOCK) {
+    const double* r4 = recp + 4 * (size_t)i;
+#if MSFL_LM_EXP == 3
+    const d3 N = mk3(0.6, 0.0, 0.8); const double d0 = 1.0 + 1e-3 * i; d3 p = mk3(1.0 + i, 2.0, 3.0);
+#else
+    const d3 N = mk3(r4[0], r4[1], r4[2]); const double d0 = r4[3];
+    d3 p;
+    if (pprime) { const size_t q = (size_t)(nc + i); p = mk3(pprime[3 * q], pprime[3 * q + 1], pprime[3 * q + 2]); }
+    else {
+      const float4 f = surf[i];                                  // curr_point: untransformed (:221)
+      p = mk3((double)f.x, (double)f.y, (double)f.z);
+      if (FILL && i < PlaneCache<BLOCK>::kPlanes) {
+        pc.nx[i] = N.x; pc.ny[i] = N.y; pc.nz[i] = N.z; pc.d0[i] = d0;
+        pc.px[i] = f.x; pc.py[i] = f.y; pc.pz[i] = f.z;
       }
     }
-    if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) continue;      // rejected correspondence
-    n_plane++;
-    const double r = dot(N, lm_rotate(T.q, p) + T.t) - d0;
-    double rho0, rho1; huber_rho_scalar(huber, r, rho0, rho1);
-    acc[0] += 0.5 * rho0;
-    acc_row(acc, R, p, N, r, sqrt(rho1));                      // :38-39
+#endif
+#if MSFL_LM_EXP == 2
+    acc[0] += N.x + d0 + p.x; n_plane++;
+#else
+    plane_row(N, d0, p);
+#endif
   }
   LM_T(t_planes_done);
 }
@@ -954,42 +999,50 @@ __device__ __noinline__ int tr_propose(TrState& tr, const SolverParams& prm) {
       for (int i = 0; i < 6; i++) tr.diagonal[i] = fmin(fmax(A[i][i], prm.min_diag), prm.max_diag);
     }
     double hs_diag[6];                     // undamped diagonal of S H S, for the model cost change below
+    // Ceres' LM strategy appends sqrt(diagonal / radius) as extra Jacobian rows, i.e. adds diagonal / radius to the
+    // normal equations: formed directly here (one division for all six), equal up to the rounding of sqrt(.)^2
+    const double inv_radius = 1.0 / tr.radius;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      const double lm = sqrt(tr.diagonal[i] / tr.radius);
-      lm2[i] = lm * lm;
+      lm2[i] = tr.diagonal[i] * inv_radius;
       hs_diag[i] = A[i][i];
       A[i][i] += lm2[i];
     }
     // factorise, solve, then step^T Hs step from the very values A was formed from (off-diagonal entries of A and the
-    // diagonal saved before damping): no second pass over the packed system in LDS
-    double L[6][6];
+    // diagonal saved before damping): no second pass over the packed system in LDS.  The factor is kept as
+    // L[i][j] (i > j) and the RECIPROCALS of its diagonal: one reciprocal square root per column instead of a
+    // square root and 2 x (5 - j) + 2 divisions (this serial, single-lane chain is latency bound: ~200 clocks each)
+    double L[6][6], dinv[6];
     bool ok = true;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
+    for (int jc = 0; jc < 6; jc++) {
+      double s = A[jc][jc];
 #pragma unroll
-      for (int j = 0; j <= i; j++) {
-        double s = A[i][j];
+      for (int k = 0; k < jc; k++) s = __builtin_fma(-L[jc][k], L[jc][k], s);
+      if (!(s > 0.0)) ok = false;
+      dinv[jc] = fast_rsqrt(s);
 #pragma unroll
-        for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
-        if (i == j) { if (!(s > 0.0)) ok = false; L[i][i] = sqrt(s); }
-        else L[i][j] = s / L[j][j];
+      for (int i = jc + 1; i < 6; i++) {
+        double v = A[i][jc];
+#pragma unroll
+        for (int k = 0; k < jc; k++) v = __builtin_fma(-L[i][k], L[jc][k], v);
+        L[i][jc] = v * dinv[jc];
       }
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) {
       double s = gs[i];
 #pragma unroll
-      for (int k = 0; k < i; k++) s -= L[i][k] * y[k];
-      y[i] = s / L[i][i];
+      for (int k = 0; k < i; k++) s = __builtin_fma(-L[i][k], y[k], s);
+      y[i] = s * dinv[i];
     }
     double step[6];
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
       double s = y[i];
 #pragma unroll
-      for (int k = i + 1; k < 6; k++) s -= L[k][i] * step[k];
-      step[i] = s / L[i][i];
+      for (int k = i + 1; k < 6; k++) s = __builtin_fma(-L[k][i], step[k], s);
+      step[i] = s * dinv[i];
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) { if (!isfinite(step[i])) ok = false; step[i] = -step[i]; }
