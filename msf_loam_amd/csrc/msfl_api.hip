@@ -357,6 +357,7 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
   bv.surf = d_surf; bv.surf_off = h->in_off.as<int>() + (B + 1);
   bv.rec_off = h->in_off.as<int>() + 2 * (B + 1);
   bv.n_scans = B; bv.n_records = n_rec;
+  bv.c0 = h_corner_off[0]; bv.s0 = h_surf_off[0]; bv.n_surf_total = h_surf_off[B] - h_surf_off[0];
   DeskewView dv{};
   if (deskew) {
     dv = *deskew;
@@ -756,6 +757,7 @@ static msfl_status stage_single(msfl_handle* h, const msfl_point* corner, int n_
   bv.surf = h->in_surf.as<float4>(); bv.surf_off = h->in_off.as<int>() + 2;
   bv.rec_off = h->in_off.as<int>() + 4;
   bv.n_scans = 1; bv.n_records = n_corner + n_surf;
+  bv.c0 = 0; bv.s0 = 0; bv.n_surf_total = n_surf;
   return MSFL_OK;
 }
 

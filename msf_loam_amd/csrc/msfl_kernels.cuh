@@ -420,6 +420,8 @@ struct BatchView {
   const int* rec_off;       // rec_off[b] = corner_off[b] + surf_off[b]
   int n_scans;
   int n_records;            // rec_off[n_scans]
+  int c0, s0;               // corner_off[0], surf_off[0] (host copies)
+  int n_surf_total;         // surf_off[n_scans] - surf_off[0]
 };
 
 // scan owning global record index g (upper bound - 1 over rec_off)
@@ -441,9 +443,12 @@ __device__ __forceinline__ int find_scan(const int* __restrict__ rec_off, int n_
   return lo;
 }
 
-// start (in doubles) of scan b's records: edges 6 doubles each, then planes 4 doubles each
-__device__ __forceinline__ size_t rec_base(const BatchView& bv, int b) {
-  return 6 * (size_t)(bv.corner_off[b] - bv.corner_off[0]) + 4 * (size_t)(bv.surf_off[b] - bv.surf_off[0]);
+// Record buffer: the PLANE records of the whole batch first (4 doubles each, so every record is one aligned 32-byte
+// line), then the edge records (6 doubles each); both are indexed by the feature's index in its cloud, so a record can be
+// written from any processing order (the binned association writes them in map-cell order).  Offsets in doubles:
+__device__ __forceinline__ size_t plane_rec_off(const BatchView& bv, int fi_surf) { return 4 * (size_t)(fi_surf - bv.s0); }
+__device__ __forceinline__ size_t edge_rec_off(const BatchView& bv, int fi_corner) {
+  return 4 * (size_t)bv.n_surf_total + 6 * (size_t)(fi_corner - bv.c0);
 }
 
 struct DeskewView {
@@ -556,13 +561,12 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
                         Vb[2] * dt - 0.5 * dv.G[2] * dt * dt);
     }
   }
-  const size_t base = rec_base(bv, b);
   if (is_edge) {
-    double* out = rec + base + 6 * (size_t)local;
+    double* out = rec + edge_rec_off(bv, bv.corner_off[b] + local);
     out[0] = fo.C.x; out[1] = fo.C.y; out[2] = fo.C.z;
     out[3] = fo.N.x; out[4] = fo.N.y; out[5] = fo.N.z;
   } else {
-    double* out = rec + base + 6 * (size_t)nc + 4 * (size_t)(local - nc);
+    double* out = rec + plane_rec_off(bv, bv.surf_off[b] + (local - nc));
     out[0] = fo.N.x; out[1] = fo.N.y; out[2] = fo.N.z; out[3] = dot(fo.N, fo.C);
   }
   if (full) {
@@ -579,13 +583,12 @@ __global__ void __launch_bounds__(256) pack_records_kernel(BatchView bv, const d
   const int local = g - bv.rec_off[b];
   const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
   const double* in = full + 6 * (size_t)g;
-  const size_t base = rec_base(bv, b);
   if (local < nc) {
-    double* out = rec + base + 6 * (size_t)local;
+    double* out = rec + edge_rec_off(bv, bv.corner_off[b] + local);
 #pragma unroll
     for (int k = 0; k < 6; k++) out[k] = in[k];
   } else {
-    double* out = rec + base + 6 * (size_t)nc + 4 * (size_t)(local - nc);
+    double* out = rec + plane_rec_off(bv, bv.surf_off[b] + (local - nc));
     out[0] = in[3]; out[1] = in[4]; out[2] = in[5]; out[3] = in[3] * in[0] + in[4] * in[1] + in[5] * in[2];
   }
 }
@@ -733,7 +736,8 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
                                               const float4* __restrict__ corner, int nc,
                                               const float4* __restrict__ surf, int ns,
                                               const double* __restrict__ pprime,   // may be null
-                                              const double* __restrict__ rec,      // this scan's records
+                                              const double* __restrict__ rec,      // this scan's edge records
+                                              const double* __restrict__ recp,     // this scan's plane records
                                               PlaneCache<BLOCK>& pc, EdgeList& el,
                                               double (&acc)[kAcc], int& n_edge, int& n_plane) {
 #pragma unroll
@@ -798,7 +802,6 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   }
   LM_T(t_edges_done);
   // planes: {N, N.C}, r = N.(R p + t) - N.C                                    lidar_factor.cc:32
-  const double* recp = rec + 6 * (size_t)nc;
   const bool use_cache = (pprime == nullptr);       // deskew keeps f64 points in global memory
   auto plane_row = [&](d3 N, double d0, d3 p) __attribute__((always_inline)) {
     if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) return;        // rejected correspondence
@@ -1138,7 +1141,8 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
   const float4* corner = bv.corner + bv.corner_off[b];
   const float4* surf = bv.surf + bv.surf_off[b];
   const size_t r0 = (size_t)bv.rec_off[b];
-  const double* rec = rec_all + rec_base(bv, b);
+  const double* rec = rec_all + edge_rec_off(bv, bv.corner_off[b]);
+  const double* recp = rec_all + plane_rec_off(bv, bv.surf_off[b]);
   const double* pprime = pprime_all ? pprime_all + 3 * r0 : nullptr;
   double* pose_g = poses + 7 * (size_t)b;
   TrState& tr = sh.tr;
@@ -1148,7 +1152,7 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
     int ne, np;
     const pose7 T = load_pose(pose_g);
     LM_T(t0);
-    evaluate_pass<BLOCK, true>(T, prm.huber, corner, nc, surf, ns, pprime, rec, s_cache, s_edges, acc, ne, np);
+    evaluate_pass<BLOCK, true>(T, prm.huber, corner, nc, surf, ns, pprime, rec, recp, s_cache, s_edges, acc, ne, np);
     LM_T(t1);
     block_reduce<BLOCK>(sh, acc, ne, np);
     LM_T(t2);
@@ -1208,7 +1212,7 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
     const pose7 T = load_pose(tr.cand);   // lane 0 overwrites go / cand only after the reduction's barrier, which every
                                            // thread reaches after this read: no barrier of its own needed
     LM_T(t0);
-    evaluate_pass<BLOCK, false>(T, prm.huber, corner, nc, surf, ns, pprime, rec, s_cache, s_edges, acc, ne, np);
+    evaluate_pass<BLOCK, false>(T, prm.huber, corner, nc, surf, ns, pprime, rec, recp, s_cache, s_edges, acc, ne, np);
     LM_T(t1);
     block_reduce<BLOCK>(sh, acc, ne, np);
     LM_T(t2);

@@ -53,7 +53,7 @@ assoc_scan2scan_kernel(BatchView bv, OdomView ov, const double* __restrict__ pos
   const int qi = q0 + threadIdx.x;
   const bool has_q = qi < nq;
   // compact records: sharp (edge) features 6 doubles {C,N}, flat (plane) features 4 doubles {N, N.C}
-  double* out = rec + rec_base(bv, b) + (qi < n_sharp ? 6 * (size_t)qi : 6 * (size_t)n_sharp + 4 * (size_t)(qi - n_sharp));
+  double* out = rec + (qi < n_sharp ? edge_rec_off(bv, bv.corner_off[b] + qi) : plane_rec_off(bv, bv.surf_off[b] + (qi - n_sharp)));
   const int out_len = qi < n_sharp ? 6 : 4;
   if (status[b] != 0) {
     if (has_q) for (int k = 0; k < out_len; k++) out[k] = 0.0;
@@ -222,7 +222,7 @@ assoc_scan2scan_wave_kernel(BatchView bv, OdomView ov, const double* __restrict_
   const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qi >= n_sharp + n_flat) return;
   const bool edge = qi < n_sharp;
-  double* out = rec + rec_base(bv, b) + (edge ? 6 * (size_t)qi : 6 * (size_t)n_sharp + 4 * (size_t)(qi - n_sharp));
+  double* out = rec + (edge ? edge_rec_off(bv, bv.corner_off[b] + qi) : plane_rec_off(bv, bv.surf_off[b] + (qi - n_sharp)));
   const int out_len = edge ? 6 : 4;
   const float4* tp = edge ? ov.last_ls + ov.last_ls_off[b] : ov.last_lf + ov.last_lf_off[b];
   const uint16_t* tr = edge ? ov.last_ls_ring + ov.last_ls_off[b] : ov.last_lf_ring + ov.last_lf_off[b];
@@ -505,7 +505,7 @@ assoc_scan2scan_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const doubl
   const int qf = tile * (kOdomBlock / L) + threadIdx.x / L;
   if (qf >= (EDGE ? n_sharp : n_flat)) return;
   constexpr int kOut = EDGE ? 6 : 4;
-  double* out = rec + rec_base(bv, b) + (EDGE ? 6 * (size_t)qf : 6 * (size_t)n_sharp + 4 * (size_t)qf);
+  double* out = rec + (EDGE ? edge_rec_off(bv, bv.corner_off[b] + qf) : plane_rec_off(bv, bv.surf_off[b] + qf));
   const int* t_off = EDGE ? ov.last_ls_off : ov.last_lf_off;
   const int s0 = t_off[b], s1 = t_off[b + 1];
   const float4* tp = (EDGE ? ov.last_ls : ov.last_lf) + s0;
