@@ -17,7 +17,6 @@
 
 #include "../../include/msfl_c_api.h"
 #include "msfl_kernels.cuh"
-#include "msfl_knn_binned.cuh"
 #include "msfl_extract.cuh"
 #include "msfl_odom.cuh"
 #include "msfl_grid.cuh"
@@ -132,9 +131,6 @@ struct msfl_handle_s {
   DevBuf in_corner, in_surf, in_off, poses, status, info, records, pprime, nn;
   DevBuf idx_cell_of, idx_count, idx_bbox, idx_cub, idx_stage;
   DevBuf knn_count;            // one u64: candidates evaluated by the counting 5-NN instantiation (timing mode 3)
-  DevBuf bin_hist, bin_tiles, bin_items, bin_out;   // binned association (msfl_knn_binned.cuh)
-  int bin_min_records = 1 << 18;   // batches with fewer records keep the per-lane kernels (MSFL_BIN_MIN_RECORDS)
-  float bin_first_radius = 0.65f;  // radius of the wave-uniform search, in gate radii (MSFL_BIN_FIRST_RADIUS); lanes that need more take the exact per-lane path
   size_t idx_count_zero = 0;   // leading ints of idx_count known to be zero on the stream
   DevBuf dk[5];
   DevBuf ex[16];
@@ -220,7 +216,7 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // descriptor is computed and kept on the device; the dense cell table has a fixed capacity
 // (default 4 M cells, MSFL_GRID_CAP_CELLS) and the device grows the cell edge if the map's bounding
 // box would need more (larger cells stay exact).
-msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi, int tile_cap) {
+msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) {
   ScopedTimer timer(h, T_INDEX);
   mi.n_input = n;
   hipStream_t st = h->stream;
@@ -259,7 +255,7 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi, 
   }
   const double radius = std::sqrt((double)h->prm.map_knn_max_sq_dist);
   if (n == 0)
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1), 0, st, mi.bbox.as<int>(), radius, cap, tile_cap, mi.gdesc.as<GridDesc>());
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1), 0, st, mi.bbox.as<int>(), radius, cap, mi.gdesc.as<GridDesc>());
   // the table is cleared / scanned over the cells actually used last time (+ margin) when known,
   // else over the full capacity; the device never indexes beyond n_cells <= cap.
   const size_t span = (size_t)cap + 1;
@@ -269,7 +265,7 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi, 
   h->idx_count_zero = 0;                  // unknown until this build has been enqueued completely
   if (span > zeroed) HIPCHK(h, hipMemsetAsync(h->idx_count.p, 0, span * sizeof(int), st));
   if (n > 0)
-    hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, (const int*)mi.bbox.as<int>(), radius, cap, tile_cap,
+    hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, (const int*)mi.bbox.as<int>(), radius, cap,
                        mi.gdesc.as<GridDesc>(), h->idx_cell_of.as<int>(), h->idx_count.as<int>());
   size_t tmp_bytes = 0;
   HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(), (int)span, st));
@@ -337,46 +333,6 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv, const double* d_poses, 
   }
 }
 
-// one data-association pass of a LARGE batch: queries binned by map tile, wave-uniform search, fit in binned order
-// (msfl_knn_binned.cuh).  Same records as s_launch_assoc, bit for bit.
-msfl_status s_launch_assoc_binned(msfl_handle* h, const BatchView& bv, const double* d_poses, const int* d_status, int n_rec) {
-  hipStream_t st = h->stream;
-  // records per chunk: at most 1024 chunks (one histogram row each), whole wavefronts per sweep
-  int chunk = std::max(4096, (div_up(n_rec, 1024) + kBinThreads - 1) / kBinThreads * kBinThreads);
-  const int n_chunks = div_up(n_rec, chunk);
-  HIPCHK(h, h->bin_hist.reserve((size_t)n_chunks * kBinTiles * sizeof(int)));
-  HIPCHK(h, h->bin_tiles.reserve((size_t)(3 * kBinTiles + 2) * sizeof(int)));
-  HIPCHK(h, h->bin_items.reserve((size_t)n_rec * sizeof(float4)));
-  HIPCHK(h, h->bin_out.reserve((size_t)n_rec * 6 * sizeof(int)));
-  int* hist = h->bin_hist.as<int>();
-  int* tile_total = h->bin_tiles.as<int>();
-  int* tile_start = tile_total + kBinTiles;
-  int* work_start = tile_start + kBinTiles + 1;
-  const GridDesc* gc = h->map_c.gdesc.as<GridDesc>();
-  const GridDesc* gs = h->map_s.gdesc.as<GridDesc>();
-  const MapView mc{gc, h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(), h->map_c.pos_of.as<int>()};
-  const MapView ms{gs, h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(), h->map_s.pos_of.as<int>()};
-  {
-    ScopedTimer timer(h, T_ASSOC);
-    hipLaunchKernelGGL(bin_count_kernel, dim3(n_chunks), dim3(kBinThreads), 0, st, bv, d_poses, d_status, gc, gs, chunk, hist);
-    hipLaunchKernelGGL(bin_prefix_kernel, dim3(kBinTiles / 64), dim3(1024), 0, st, hist, n_chunks, tile_total);
-    hipLaunchKernelGGL(bin_finalize_kernel, dim3(1), dim3(1024), 0, st, (const int*)tile_total, tile_start, work_start);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(n_chunks), dim3(kBinThreads), 0, st, bv, d_poses, d_status, gc, gs, chunk,
-                       (const int*)hist, (const int*)tile_start, h->bin_items.as<float4>());
-    const int max_work = div_up(n_rec, kBinSlice) + kBinTiles;       // slices: every tile may end with a partial one
-    hipLaunchKernelGGL(knn5_binned_kernel, dim3(max_work), dim3(kBinBlock), 0, st, (const float4*)h->bin_items.as<float4>(),
-                       (const int*)tile_start, (const int*)work_start, mc, ms, h->prm.map_knn_max_sq_dist,
-                       h->bin_first_radius * std::sqrt(h->prm.map_knn_max_sq_dist), h->bin_out.as<int>());
-  }
-  {
-    ScopedTimer timer(h, T_FIT);
-    hipLaunchKernelGGL(fit_binned_kernel, dim3(div_up(n_rec, kAssocBlock)), dim3(kAssocBlock), 0, st, bv, (const int*)tile_start,
-                       (const int*)h->bin_out.as<int>(), h->map_c.sorted.as<float4>(), h->map_s.sorted.as<float4>(),
-                       h->prm.line_eigen_ratio, h->prm.plane_tolerance, h->records.as<double>());
-  }
-  return MSFL_OK;
-}
-
 // Core of stage C.  All pointers are device pointers except the offsets (host).
 msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner, const int* h_corner_off,
                                   const float4* d_surf, const int* h_surf_off, double* d_poses, int* d_status,
@@ -411,14 +367,7 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
   const SolverParams sp = solver_params(h->prm, 0);
   for (int it = 0; it < h->prm.outer_iterations; it++) {
     if (n_rec > 0) {
-      // large plain batches: binned, wave-uniform association; the candidate-counting mode (timing 3), the deskew branch
-      // and small calls stay on the per-lane kernels (identical results)
-      if (!deskew && h->timing != 3 && n_rec >= h->bin_min_records) {
-        msfl_status bs = s_launch_assoc_binned(h, bv, d_poses, d_status, n_rec);
-        if (bs) return bs;
-      } else {
-        s_launch_assoc(h, bv, d_poses, d_status, deskew != nullptr, dv, n_rec);
-      }
+      s_launch_assoc(h, bv, d_poses, d_status, deskew != nullptr, dv, n_rec);
     }
     {
       ScopedTimer timer(h, T_SOLVE);
@@ -511,8 +460,6 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
   if (const char* e = std::getenv("MSFL_GRID_CAP_CELLS")) { const int c = std::atoi(e); if (c >= 8 && c <= (1 << 28)) h->grid_cap_cells = c; }
   if (const char* e = std::getenv("MSFL_H2D_CHUNK_SCANS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_chunk_scans = c; }
   if (const char* e = std::getenv("MSFL_ODOM_BRUTE")) h->odom_force_brute = std::atoi(e) != 0;
-  if (const char* e = std::getenv("MSFL_BIN_MIN_RECORDS")) { const long long c = std::atoll(e); h->bin_min_records = (int)std::min<long long>(std::max<long long>(c, 1), INT32_MAX); }
-  if (const char* e = std::getenv("MSFL_BIN_FIRST_RADIUS")) { const double r = std::atof(e); if (r > 0.0 && r <= 1.0) h->bin_first_radius = (float)r; }
   *out = h;
   return MSFL_OK;
 }
@@ -527,15 +474,6 @@ void msfl_destroy(msfl_handle* h) {
     if (v[5]) fprintf(stderr, "[lm profile] per solve (100 MHz ticks): eval %.0f reduce %.0f serial %.0f total %.0f passes %.2f solves %llu\n",
                       (double)v[0] / v[5], (double)v[1] / v[5], (double)v[2] / v[5], (double)v[3] / v[5], (double)v[4] / v[5], v[5]);
     if (v[5]) fprintf(stderr, "[lm profile] lane-0 logic: tr_decide %.0f tr_propose %.0f ticks per solve\n", (double)v[6] / v[5], (double)v[7] / v[5]);
-  }
-#endif
-#if MSFL_BIN_EXP == 2
-  {
-    unsigned long long v[8] = {0};
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(msfl::g_bin_dbg), sizeof(v));
-    if (v[0]) fprintf(stderr, "[bin dbg] batches %llu: candidates/batch %.1f, lanes/batch %.1f, hard %.4f, tied %.5f, overflowed batches %.5f\n",
-                      v[0], (double)v[1] / v[0], (double)v[2] / v[0], (double)v[3] / v[2], (double)v[4] / v[2], (double)v[5] / v[0]);
   }
 #endif
   (void)hipSetDevice(h->device);
@@ -553,8 +491,7 @@ void msfl_destroy(msfl_handle* h) {
   DevBuf* bufs[] = {&h->map_c.sorted, &h->map_c.cell_start, &h->map_s.sorted, &h->map_s.cell_start, &h->map_c.pos_of, &h->map_s.pos_of,
                     &h->map_c.gdesc, &h->map_s.gdesc, &h->map_c.bbox, &h->map_s.bbox, &h->in_corner,
                     &h->in_surf, &h->in_off, &h->poses, &h->status, &h->info, &h->records, &h->pprime, &h->nn,
-                    &h->idx_cell_of, &h->idx_count, &h->idx_bbox, &h->idx_cub, &h->idx_stage, &h->knn_count,
-                    &h->bin_hist, &h->bin_tiles, &h->bin_items, &h->bin_out};
+                    &h->idx_cell_of, &h->idx_count, &h->idx_bbox, &h->idx_cub, &h->idx_stage, &h->knn_count};
   for (auto* b : bufs) b->release();
   for (auto& b : h->dk) b.release();
   for (auto& b : h->ex) b.release();
@@ -650,8 +587,8 @@ msfl_status msfl_set_map(msfl_handle* h, const msfl_point* corner, int n_corner,
     if (n_surf) HIPCHK(h, hipMemcpyAsync(stage + n_corner, surf, (size_t)n_surf * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     dc = stage; ds = stage + n_corner;
   }
-  s = build_index(h, dc, n_corner, h->map_c, kBinTilesCorner); if (s) return s;
-  s = build_index(h, ds, n_surf, h->map_s, kBinTiles - kBinTilesCorner); if (s) return s;
+  s = build_index(h, dc, n_corner, h->map_c); if (s) return s;
+  s = build_index(h, ds, n_surf, h->map_s); if (s) return s;
   // host arrays were staged with asynchronous copies from pageable memory: they must have been read
   // before the caller may touch them again.  Device-resident maps stay fully asynchronous.
   if (mem == MSFL_MEM_HOST) HIPCHK(h, hipStreamSynchronize(h->stream));

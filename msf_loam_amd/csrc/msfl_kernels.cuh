@@ -41,9 +41,6 @@ struct GridDesc {
   int reach;          // cells scanned on each side of the query cell (1)
   int want_cells;     // cells the bbox needs at the base cell edge (saturated); host feedback for the next build
   float cell2, cellx2;  // (1 / inv_cell)^2 and (1 / inv_cell_x)^2 in f32: every query needs them, computed once per build
-  // Tiling for the binned (throughput) association, msfl_knn_binned.cuh: a tile is a block of tk x tk cells in (y, z)
-  // and tk * kGridXSub cells in x, ntx * nty * ntz <= the tile capacity given to the build
-  int tk, ntx, nty, ntz;
 };
 
 // order-preserving float <-> int encoding for atomicMin/Max
@@ -114,30 +111,16 @@ __device__ __forceinline__ void grid_desc_squares(GridDesc& g) {
   const float cell = 1.0f / g.inv_cell, cellx = 1.0f / g.inv_cell_x;
   g.cell2 = cell * cell; g.cellx2 = cellx * cellx;
 }
-// smallest tile block (up to the 1/8 growth steps) whose tile count fits `tile_cap`
-__device__ __forceinline__ void grid_desc_tiles(GridDesc& g, int tile_cap) {
-  int tk = 1;
-  for (;;) {
-    g.ntx = (g.dx + tk * kGridXSub - 1) / (tk * kGridXSub);
-    g.nty = (g.dy + tk - 1) / tk;
-    g.ntz = (g.dz + tk - 1) / tk;
-    if ((long long)g.ntx * g.nty * g.ntz <= (long long)tile_cap) break;
-    tk += tk < 8 ? 1 : tk / 8;
-  }
-  g.tk = tk;
-}
-
 // bbox -> grid descriptor, entirely on the device so that msfl_set_map needs no host round trip.
 // Cell edge = 1.001 * acceptance radius, grown by 26 % steps until the dense table fits `cap_cells`
 // (larger cells stay exact).  An empty cloud yields n_cells = 1, n_pts = 0.
-__device__ __forceinline__ GridDesc grid_desc_from_bbox(const int* __restrict__ bbox, double radius, int cap_cells, int tile_cap) {
+__device__ __forceinline__ GridDesc grid_desc_from_bbox(const int* __restrict__ bbox, double radius, int cap_cells) {
   GridDesc g;
   const int b0 = bbox[0];
   g.n_pts = 0; g.reach = 1;
   if (b0 == 0x7fffffff) {            // no finite point
     g.ox = g.oy = g.oz = 0.f; g.inv_cell = 1.f; g.inv_cell_x = (float)kGridXSub; g.dx = g.dy = g.dz = 1; g.n_cells = 1; g.want_cells = 1;
     grid_desc_squares(g);
-    grid_desc_tiles(g, tile_cap);
     return g;
   }
   float mn[3], mx[3];
@@ -164,7 +147,6 @@ __device__ __forceinline__ GridDesc grid_desc_from_bbox(const int* __restrict__ 
   g.dx = dims[0]; g.dy = dims[1]; g.dz = dims[2];
   g.n_cells = g.dx * g.dy * g.dz;
   grid_desc_squares(g);
-  grid_desc_tiles(g, tile_cap);
   return g;
 }
 
@@ -174,19 +156,19 @@ __device__ __forceinline__ void grid_bbox_rearm(int* __restrict__ bbox) {
 
 // Only launched for an EMPTY cloud (nothing else runs then); a non-empty build derives the descriptor
 // inside grid_count_kernel and re-arms the bbox in grid_scatter_kernel.
-__global__ void grid_setup_kernel(int* __restrict__ bbox, double radius, int cap_cells, int tile_cap, GridDesc* __restrict__ out) {
-  *out = grid_desc_from_bbox(bbox, radius, cap_cells, tile_cap);
+__global__ void grid_setup_kernel(int* __restrict__ bbox, double radius, int cap_cells, GridDesc* __restrict__ out) {
+  *out = grid_desc_from_bbox(bbox, radius, cap_cells);
   grid_bbox_rearm(bbox);
 }
 
 // Every workgroup derives the (identical) descriptor from the finished bbox itself: one launch less
 // per build than a separate one-thread setup kernel; workgroup 0 publishes it.
 __global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restrict__ pts, int n, const int* __restrict__ bbox,
-                                                          double radius, int cap_cells, int tile_cap, GridDesc* __restrict__ gout,
+                                                          double radius, int cap_cells, GridDesc* __restrict__ gout,
                                                           int* __restrict__ cell_of, int* __restrict__ count) {
   __shared__ GridDesc s_g;
   if (threadIdx.x == 0) {
-    s_g = grid_desc_from_bbox(bbox, radius, cap_cells, tile_cap);
+    s_g = grid_desc_from_bbox(bbox, radius, cap_cells);
     if (blockIdx.x == 0) *gout = s_g;
   }
   __syncthreads();
@@ -462,7 +444,7 @@ __device__ __forceinline__ int find_scan(const int* __restrict__ rec_off, int n_
 
 // Record buffer: the PLANE records of the whole batch first (4 doubles each, so every record is one aligned 32-byte
 // line), then the edge records (6 doubles each); both are indexed by the feature's index in its cloud, so a record can be
-// written from any processing order (the binned association writes them in map-cell order).  Offsets in doubles:
+// written from any processing order.  Offsets in doubles:
 __device__ __forceinline__ size_t plane_rec_off(const BatchView& bv, int fi_surf) { return 4 * (size_t)(fi_surf - bv.s0); }
 __device__ __forceinline__ size_t edge_rec_off(const BatchView& bv, int fi_corner) {
   return 4 * (size_t)bv.n_surf_total + 6 * (size_t)(fi_corner - bv.c0);
