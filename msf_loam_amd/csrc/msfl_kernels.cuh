@@ -824,8 +824,11 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
     for (; i < min(ns, PlaneCache<BLOCK>::kPlanes); i += BLOCK)
       plane_row(mk3(pc.nx[i], pc.ny[i], pc.nz[i]), pc.d0[i], mk3((double)pc.px[i], (double)pc.py[i], (double)pc.pz[i]));
   }
-  // (b) the streamed rest (everything in the FILL pass).  Software-pipelining these loads two iterations ahead was
-  // measured SLOWER (0.279 vs 0.229 ms per solve): the pass is not waiting for its record loads.
+  // (b) the streamed rest (everything in the FILL pass).  The solve is bound by these re-reads: ~1 GB per launch at
+  // ~4.4 TB/s with all 1 024 solves resident (PMC r02).  Measured and rejected: software pipelining the loads 1 / 2 / 3
+  // trips ahead, branch-free (0.249 / 0.258 / 0.264 vs 0.233 ms: more bytes in flight do not help a bandwidth-bound
+  // pass); solving the batch in 2 / 4 launches of fewer scans (0.41 / 0.71 ms: with fewer resident workgroups the
+  // pass becomes latency bound instead).
   for (; i < ns; i += BLOCK) {
     const double* r4 = recp + 4 * (size_t)i;
 #if MSFL_LM_EXP == 3
