@@ -345,14 +345,25 @@ static inline float dist2f(const orc_point* a, const float q[3]) {
   return r;
 }
 
+/* Behaviours the reference's toolchain leaves UNSPECIFIED, switchable for the sensitivity tests only
+   (tests/test_oracle_unspecified.py; 0 = the documented choice):
+     sort ties    std::sort of sector indices by curvature is unstable (msf_loam_node.cc:263-267)
+     kNN ties     FLANN returns equal distances in an order that depends on its tree traversal (mapping_scan_matcher.cc:125)
+     atan2        unqualified atan2(float, float) may bind to the float or the double overload (msf_loam_node.cc:131,139) */
+static int g_sort_ties_reverse = 0, g_knn_ties_reverse = 0, g_atan2_float = 0;
+void orc_set_unspecified(int sort_ties_reverse, int knn_ties_reverse, int atan2_float) {
+  g_sort_ties_reverse = sort_ties_reverse; g_knn_ties_reverse = knn_ties_reverse; g_atan2_float = atan2_float;
+}
+static inline int idx_after(int a, int b) { return g_knn_ties_reverse ? a < b : a > b; }   /* a loses the tie against b */
+
 /* sorted insertion, ties broken by ascending index */
 static inline void knn_insert(int k, int* idx, float* d2, int* count, float d, int i) {
   int c = *count;
   if (c == k) {
-    if (d > d2[k - 1] || (d == d2[k - 1] && i > idx[k - 1])) return;
+    if (d > d2[k - 1] || (d == d2[k - 1] && idx_after(i, idx[k - 1]))) return;
   }
   int pos = (c < k) ? c : k - 1;
-  while (pos > 0 && (d2[pos - 1] > d || (d2[pos - 1] == d && idx[pos - 1] > i))) {
+  while (pos > 0 && (d2[pos - 1] > d || (d2[pos - 1] == d && idx_after(idx[pos - 1], i)))) {
     d2[pos] = d2[pos - 1]; idx[pos] = idx[pos - 1]; pos--;
   }
   d2[pos] = d; idx[pos] = i;
@@ -1043,7 +1054,8 @@ static int curv_cmp(const void* a, const void* b) {
   const curv_key* x = (const curv_key*)a; const curv_key* y = (const curv_key*)b;
   if (x->c < y->c) return -1;
   if (x->c > y->c) return 1;
-  return (x->i > y->i) - (x->i < y->i);     /* tie-break: ascending index (std::sort is unstable) */
+  const int o = (x->i > y->i) - (x->i < y->i);     /* tie-break: ascending index (std::sort is unstable) */
+  return g_sort_ties_reverse ? -o : o;
 }
 
 static inline double gap2(const orc_point* a, const orc_point* b) {
@@ -1084,11 +1096,11 @@ int orc_extract_features(const orc_point* pts_in, const uint16_t* ring_in, int n
   double last_rel[ORC_MAX_RINGS];
   for (int r = 0; r < ORC_MAX_RINGS; r++) last_rel[r] = -1;
   const double two_pi = 2 * M_PI;
-  double start_ori = -atan2((double)valid[0].y, (double)valid[0].x);       /* :131 */
+  double start_ori = g_atan2_float ? -(double)atan2f(valid[0].y, valid[0].x) : -atan2((double)valid[0].y, (double)valid[0].x);       /* :131 */
   for (int i = 0; i < nv; i++) {
     orc_point p = valid[i];
     int r = vring[i];
-    double ori = -atan2((double)p.y, (double)p.x);                          /* :139 */
+    double ori = g_atan2_float ? -(double)atan2f(p.y, p.x) : -atan2((double)p.y, (double)p.x);                          /* :139 */
     double rel = fmod(ori - start_ori + two_pi, two_pi);                    /* :142 */
     if (rel < last_rel[r]) rel += two_pi;                                   /* :145-148 */
     last_rel[r] = rel;

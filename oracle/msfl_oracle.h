@@ -27,6 +27,9 @@ extern "C" {
 
 typedef struct { float x, y, z, t; } orc_point;   /* pcl::PointXYZI; t == intensity == rel. time */
 
+/* Sensitivity tests only: flip the three choices the reference's toolchain leaves unspecified (0 = documented choice). */
+void orc_set_unspecified(int sort_ties_reverse, int knn_ties_reverse, int atan2_float);
+
 /* ---- math restatements -------------------------------------------------------------------- */
 
 /* Eigen::Quaterniond * Vector3d (QuaternionBase::_transformVector). q = [qx qy qz qw]. */
