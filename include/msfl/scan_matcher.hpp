@@ -110,6 +110,25 @@ struct DeskewInputs {
   Vector3d gravity_vector{{0, 0, 0}};
 };
 
+// What the scan matcher reads of the reference's IMU types (views with the reference's member names; the
+// pre-integration itself — imu_fusion/integration_base.h — is outside the hot path):
+//   IntegrationBase   integration_base.h:62-69: per IMU sample the cumulative time and the pre-integrated
+//                     rotation / position, read by GetDeltaQP (scan_undistortion.cc:22-42)
+//   RobotState        slam/estimator/estimator.h:10-19
+using Quaterniond = std::array<double, 4>;                             // [x y z w] like Eigen::Quaterniond::coeffs()
+struct IntegrationBase {
+  std::vector<double> sum_dt_buf_;
+  std::vector<Vector3d> delta_p_buf_;
+  std::vector<Quaterniond> delta_q_buf_;
+};
+struct RobotState {
+  double time = 0.0;
+  Vector3d p{{0, 0, 0}}, v{{0, 0, 0}};
+  Quaterniond q{{0, 0, 0, 1}};
+  Vector3d bg{{0, 0, 0}}, ba{{0, 0, 0}};
+  std::shared_ptr<IntegrationBase> imu_preintegration;
+};
+
 namespace detail {
 inline void Check(msfl_status s, msfl_handle* h, const char* what) {
   // the reference aborts through glog CHECK on invariant violations; here: an exception
@@ -206,6 +225,49 @@ class MappingScanMatcher : public ScanMatcher {
     detail::Check(st, h_, "msfl_match_scan2map");
     *pose_estimate_map_scan2world = Rigid3d(v);
     return true;
+  }
+
+  // The reference's own eight-parameter signature (mapping_scan_matcher.h:14-21), argument for argument.
+  //   !is_initialized: LiDAR-only branch (.cc:96,123); preintegration / gravity_vector / prev_state are not read.
+  //   is_initialized : GetDeltaQP(preintegration, point.intensity) for every feature point (.cc:112-116,182-186) runs on
+  //                    the GPU (msfl_delta_qp), then the Deskew factors with the velocity block held constant (.cc:94).
+  //                    The IMU-only pre-solve the reference runs first (.cc:35-59: one IMUFactor, 15 residuals, CPU,
+  //                    out of scope per SURVEY.md 8f N3) is NOT repeated here: *pose_estimate_map_scan2world and *velocity
+  //                    are taken as its outputs (pose_j, bias_j.head<3>()), which is what the reference's loop reads (.cc:83,107).
+  // A feature time outside the pre-integration span aborts in the reference (CHECK, scan_undistortion.cc:26-30): exception here.
+  bool MatchScan2Map(const TimestampedPointCloud<PointType>& cloud_map,
+                     const TimestampedPointCloud<PointType>& scan_curr,
+                     const bool is_initialized,
+                     const std::shared_ptr<IntegrationBase>& preintegration,
+                     const Vector3d& gravity_vector,
+                     const RobotState& prev_state,
+                     Rigid3d* pose_estimate_map_scan2world,
+                     Vector3d* velocity) {
+    (void)prev_state;                                                  // only feeds the pre-solve and a log line (.cc:27)
+    if (!is_initialized)
+      return MatchScan2Map(cloud_map, scan_curr, false, nullptr, pose_estimate_map_scan2world, velocity);
+    if (!preintegration || preintegration->sum_dt_buf_.size() < 2 ||
+        preintegration->delta_q_buf_.size() != preintegration->sum_dt_buf_.size() ||
+        preintegration->delta_p_buf_.size() != preintegration->sum_dt_buf_.size())
+      throw std::invalid_argument("MatchScan2Map: is_initialized needs a pre-integration with >= 2 samples");
+    msfl_preintegration pre;
+    pre.sum_dt = preintegration->sum_dt_buf_.data();
+    pre.delta_q = preintegration->delta_q_buf_[0].data();
+    pre.delta_p = preintegration->delta_p_buf_[0].data();
+    pre.n = static_cast<int>(preintegration->sum_dt_buf_.size());
+    DeskewInputs d;
+    d.gravity_vector = gravity_vector;
+    const std::vector<msfl_point> c = detail::Pack(*scan_curr.cloud_corner_less_sharp);
+    const std::vector<msfl_point> s = detail::Pack(*scan_curr.cloud_surf_less_flat);
+    d.corner_delta_q.resize(c.size()); d.corner_delta_p.resize(c.size());
+    d.surf_delta_q.resize(s.size()); d.surf_delta_p.resize(s.size());
+    if (!c.empty())
+      detail::Check(msfl_delta_qp(h_, &pre, c.data(), static_cast<int>(c.size()), d.corner_delta_q[0].data(), d.corner_delta_p[0].data(),
+                                  MSFL_MEM_HOST), h_, "msfl_delta_qp (corner)");
+    if (!s.empty())
+      detail::Check(msfl_delta_qp(h_, &pre, s.data(), static_cast<int>(s.size()), d.surf_delta_q[0].data(), d.surf_delta_p[0].data(),
+                                  MSFL_MEM_HOST), h_, "msfl_delta_qp (surf)");
+    return MatchScan2Map(cloud_map, scan_curr, true, &d, pose_estimate_map_scan2world, velocity);
   }
 };
 

@@ -1,7 +1,10 @@
 // Exercises the C++ host mirror (include/msfl/scan_matcher.hpp) end to end on the GPU.
 // usage: host_api_check <in.bin> <out.bin>
 //   in : i32 n_scan_pts | pts(n x (4 f32)) | ring(n x u16) | i32 mc | map corner (mc x 4 f32) | i32 ms | map surf | 7 f64 guess
+//        | i32 n_pre | sum_dt (n_pre f64) | delta_q (n_pre x 4 f64) | delta_p (n_pre x 3 f64) | 3 f64 velocity | 3 f64 gravity
 //   out: 7 f64 map pose | 7 f64 odom pose | i32 odom_ok | i32 n_sharp n_less_sharp n_flat n_less_flat
+//        | 7 f64 map pose of the reference-signature (8-argument) call, is_initialized = false
+//        | 7 f64 map pose of the 8-argument call, is_initialized = true (deskew branch)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -21,6 +24,9 @@ int main(int argc, char** argv) {
   const int mc = rd<int>(f, 1)[0]; auto mcp = rd<float>(f, 4 * (std::size_t)mc);
   const int ms = rd<int>(f, 1)[0]; auto msp = rd<float>(f, 4 * (std::size_t)ms);
   auto guess = rd<double>(f, 7);
+  const int n_pre = rd<int>(f, 1)[0];
+  auto sum_dt = rd<double>(f, n_pre); auto dq = rd<double>(f, 4 * (std::size_t)n_pre); auto dp = rd<double>(f, 3 * (std::size_t)n_pre);
+  auto vel_in = rd<double>(f, 3); auto grav = rd<double>(f, 3);
   fclose(f);
   msfl::PointCloud<msfl::PointXYZIRT> cloud;
   for (int i = 0; i < n; ++i) cloud.push_back({pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], 0.f, ring[i], 0.f});
@@ -40,12 +46,30 @@ int main(int argc, char** argv) {
   msfl::OdometryScanMatcher odo(0);
   msfl::Rigid3d rel({{0.05, -0.03, 0.01}}, {{0, 0, 0.005, 0.9999875}});
   const bool odo_ok = odo.MatchScan2Scan(scan, scan, &rel);
+  // the reference's own signature (mapping_scan_matcher.h:14-21): both branches
+  auto pre = std::make_shared<msfl::IntegrationBase>();
+  pre->sum_dt_buf_ = sum_dt;
+  for (int i = 0; i < n_pre; ++i) {
+    pre->delta_q_buf_.push_back({{dq[4 * i], dq[4 * i + 1], dq[4 * i + 2], dq[4 * i + 3]}});
+    pre->delta_p_buf_.push_back({{dp[3 * i], dp[3 * i + 1], dp[3 * i + 2]}});
+  }
+  msfl::RobotState prev;
+  prev.imu_preintegration = pre;
+  const msfl::Vector3d gravity{{grav[0], grav[1], grav[2]}};
+  msfl::Rigid3d pose8(std::array<double, 7>{{guess[0], guess[1], guess[2], guess[3], guess[4], guess[5], guess[6]}});
+  msfl::Vector3d vel8{{0, 0, 0}};
+  const bool ok8 = mapper.MatchScan2Map(map, cur, false, pre, gravity, prev, &pose8, &vel8);
+  msfl::Rigid3d pose8d(std::array<double, 7>{{guess[0], guess[1], guess[2], guess[3], guess[4], guess[5], guess[6]}});
+  msfl::Vector3d vel8d{{vel_in[0], vel_in[1], vel_in[2]}};
+  const bool ok8d = mapper.MatchScan2Map(map, cur, true, pre, gravity, prev, &pose8d, &vel8d);
   FILE* o = fopen(argv[2], "wb");
   auto v = pose.ToVector7(); auto w = rel.ToVector7();
   fwrite(v.data(), 8, 7, o); fwrite(w.data(), 8, 7, o);
   const int ints[5] = {odo_ok ? 1 : 0, (int)scan.cloud_corner_sharp->size(), (int)scan.cloud_corner_less_sharp->size(),
                        (int)scan.cloud_surf_flat->size(), (int)scan.cloud_surf_less_flat->size()};
   fwrite(ints, 4, 5, o);
+  auto v8 = pose8.ToVector7(); auto v8d = pose8d.ToVector7();
+  fwrite(v8.data(), 8, 7, o); fwrite(v8d.data(), 8, 7, o);
   fclose(o);
-  return ok ? 0 : 3;
+  return (ok && ok8 && ok8d) ? 0 : 3;
 }

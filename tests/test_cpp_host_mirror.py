@@ -45,6 +45,12 @@ def test_cpp_host_mirror_matches_ctypes_path(gpu, tmp_path):
         f.write(struct.pack("<i", len(mc))); f.write(mc.astype("<f4").tobytes())
         f.write(struct.pack("<i", len(ms))); f.write(ms.astype("<f4").tobytes())
         f.write(np.asarray(guess, "<f8").tobytes())
+        from tests.test_deskew import _preintegration
+        t, dq, dp = _preintegration(n=60, span=0.25)           # relative times of a scan reach 0.2 s when a ring wraps (msf_loam_node.cc:145-148)
+        vel, grav = np.array([0.4, -0.2, 0.05]), np.array([0.0, 0.0, 9.81])
+        f.write(struct.pack("<i", len(t)))
+        for a in (t, dq, dp, vel, grav):
+            f.write(np.asarray(a, "<f8").tobytes())
     subprocess.check_call([EXE, str(fin), str(fout)])
     raw = open(fout, "rb").read()
     pose_cpp = np.frombuffer(raw[:56], "<f8"); rel_cpp = np.frombuffer(raw[56:112], "<f8")
@@ -57,3 +63,14 @@ def test_cpp_host_mirror_matches_ctypes_path(gpu, tmp_path):
     assert odo_ok == 1
     dt, dr = synth.pose_error(rel_cpp, np.array([0, 0, 0, 0, 0, 0, 1.0]))
     assert dt < 2e-3 and dr < 2e-4      # a scan registered against itself returns to identity
+    # the reference-signature (8-argument) overload: LiDAR-only branch == the 6-argument call, deskew branch == the ctypes
+    # chain msfl_delta_qp -> msfl_match_scan2map_deskew, both bit for bit
+    pose8 = np.frombuffer(raw[132:188], "<f8"); pose8d = np.frombuffer(raw[188:244], "<f8")
+    assert np.array_equal(pose8, pose_py)
+    corner, surf = f["full"][f["less_sharp"]], f["full"][f["less_flat"]]
+    sc, cdq, cdp = gpu.delta_qp(t, dq, dp, corner)
+    ss, sdq, sdp = gpu.delta_qp(t, dq, dp, surf)
+    assert sc == 0 and ss == 0
+    s, pose_d, _ = gpu.match_scan2map_deskew(corner, surf, cdq, cdp, sdq, sdp, vel, grav, guess)
+    assert s == 0 and np.array_equal(pose8d, pose_d)
+    assert not np.array_equal(pose8d, pose8)
