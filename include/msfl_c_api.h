@@ -355,7 +355,8 @@ msfl_status msfl_extract_features_batch(msfl_handle* h, int n_scans,
 
 /* Centroid voxel filter with PCL VoxelGrid semantics (leaf cube, centroid of x,y,z,t per
    occupied voxel, output ordered by voxel index).  out has capacity n; *n_out receives the
-   count. */
+   count.  A non-finite point is refused with MSFL_BAD_ARG (pcl::VoxelGrid would drop it; the
+   reference's clouds never hold one, msf_loam_node.cc:85-111), also in the batch form. */
 msfl_status msfl_voxel_downsample(msfl_handle* h,
                                   const msfl_point* pts, int n, float leaf,
                                   msfl_point* out, int* n_out, msfl_mem mem);
@@ -368,7 +369,8 @@ msfl_status msfl_voxel_downsample(msfl_handle* h,
    count == NULL: the whole region.  `off` is a host array (like every batch call), pts / idx /
    count / out follow `mem`.  The filtered clouds are written back to back into `out` (capacity
    off[n]-off[0] points) and out_off (HOST, n_clouds+1) receives their boundaries; the call
-   synchronises once to deliver them.  A cloud without a finite point yields no output. */
+   synchronises once to deliver them.  A cloud holding a non-finite point makes the call return
+   MSFL_BAD_ARG (the clouds before it are still delivered). */
 msfl_status msfl_voxel_downsample_batch(msfl_handle* h, int n_clouds,
                                         const msfl_point* pts, const int* idx, const int* off,
                                         const int* count, float leaf,

@@ -5,7 +5,8 @@
 // There is NO CPU fallback: every entry point either runs the gfx950 kernels or returns an
 // error status.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -268,9 +269,9 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
     hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, (const int*)mi.bbox.as<int>(), radius, cap,
                        mi.gdesc.as<GridDesc>(), h->idx_cell_of.as<int>(), h->idx_count.as<int>());
   size_t tmp_bytes = 0;
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(), (int)span, st));
+  HIPCHK(h, rocprim::exclusive_scan(nullptr, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(), 0, (size_t)((int)span), rocprim::plus<int>(), st));
   HIPCHK(h, h->idx_cub.reserve(tmp_bytes));
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(h->idx_cub.p, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(), (int)span, st));
+  HIPCHK(h, rocprim::exclusive_scan(h->idx_cub.p, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(), 0, (size_t)((int)span), rocprim::plus<int>(), st));
   if (n > 0)
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, h->idx_cell_of.as<int>(),
                        mi.cell_start.as<int>(), h->idx_count.as<int>(), mi.sorted.as<float4>(), mi.pos_of.as<int>(),

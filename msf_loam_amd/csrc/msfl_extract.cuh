@@ -629,11 +629,15 @@ __global__ void __launch_bounds__(256) extract_compact_kernel(ExtractView v, con
 // ---------------------------------------------------------------------------------------------
 struct VoxelDesc { float inv_leaf; int min_b[3]; int div_b[3]; };
 
+// *bad |= 1 when a point is not finite: pcl::VoxelGrid drops such points (the reference never feeds it one:
+// RemoveInvalidPointsFromCloud, msf_loam_node.cc:85-111); here the call is refused (MSFL_BAD_ARG) instead of
+// silently averaging NaN into a centroid
 __global__ void __launch_bounds__(256) voxel_key_kernel(const float4* __restrict__ pts, int n, VoxelDesc d,
-                                                         unsigned long long* __restrict__ keys) {
+                                                         unsigned long long* __restrict__ keys, int* __restrict__ bad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 p = pts[i];
+  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) atomicOr(bad, 1);
   const int i0 = (int)(floorf(p.x * d.inv_leaf) - (float)d.min_b[0]);
   const int i1 = (int)(floorf(p.y * d.inv_leaf) - (float)d.min_b[1]);
   const int i2 = (int)(floorf(p.z * d.inv_leaf) - (float)d.min_b[2]);
@@ -690,11 +694,16 @@ __global__ void __launch_bounds__(256) voxel_batch_desc_kernel(VoxelBatchView v,
   const int cap = v.off[b + 1] - v.off[b];
   const int n = v.count ? min(max(v.count[b], 0), cap) : cap;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  __shared__ int s_nonfinite;
+  if (threadIdx.x == 0) s_nonfinite = 0;
+  __syncthreads();
   for (int k = threadIdx.x; k < n; k += 256) {
     const float4 p = vb_point(v, b, k);
     if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
       mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
       mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    } else {
+      s_nonfinite = 1;                        // refused below: see voxel_key_kernel
     }
   }
 #pragma unroll
@@ -717,6 +726,7 @@ __global__ void __launch_bounds__(256) voxel_batch_desc_kernel(VoxelBatchView v,
       cells *= d.div_b[a];
       if (cells > 0x7fffffffLL) d.bad = 1;            // leaf too small for the extent (PCL would skip filtering)
     }
+    if (s_nonfinite) d.bad = 3;
     desc[b] = d;
     n_valid[b] = d.bad ? 0 : n;
     if (!d.bad && n > 0) atomicMax(max_cells, (int)cells);

@@ -168,3 +168,23 @@ def test_randomised_odd_scans_bit_exact(gpu, oracle, seed):
     fo = oracle.extract_features(pts, ring)
     f = gpu.extract_features(pts, ring, allow=(capi.BAD_ARG,))
     _check(f, fo)
+
+
+def test_voxel_filters_refuse_non_finite_points(gpu):
+    """ADVICE r01: a NaN / Inf point must not be averaged into a centroid (pcl::VoxelGrid drops it on non-dense
+    clouds).  The reference never produces one (RemoveInvalidPointsFromCloud); the public filters refuse the call."""
+    from msf_loam_amd import capi
+    rng = np.random.default_rng(1)
+    pts = np.zeros((500, 4), np.float32)
+    pts[:, :3] = rng.uniform(-5, 5, (500, 3))
+    assert len(gpu.voxel_downsample(pts, 0.4)) > 0
+    for bad in (np.nan, np.inf, -np.inf):
+        q = pts.copy(); q[123, 1] = bad
+        with pytest.raises(capi.MsflError) as e:
+            gpu.voxel_downsample(q, 0.4)
+        assert e.value.status == capi.BAD_ARG
+        with pytest.raises(capi.MsflError) as e:
+            gpu.voxel_downsample_batch(np.concatenate([pts, q]), np.array([0, 500, 1000], np.int32), 0.4)
+        assert e.value.status == capi.BAD_ARG
+    out, off = gpu.voxel_downsample_batch(np.concatenate([pts, pts]), np.array([0, 500, 1000], np.int32), 0.4)
+    assert off[1] == off[2] - off[1] == len(gpu.voxel_downsample(pts, 0.4))
