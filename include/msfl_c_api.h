@@ -409,6 +409,8 @@ msfl_status msfl_delta_qp(msfl_handle* h, const msfl_preintegration* pre,
 /* The deskew pass of LaserMapping (laser_mapping.cc:197-211), in place on one cloud:
      p <- (dq(t) * p + R_odom^-1 * (velocity * t - 0.5 * gravity * t * t) + dp(t)).cast<float>()
    rot_odom_xyzw = pose_odom_scan2world_.rotation() as [qx qy qz qw]. */
+/* Both in-place passes are all-or-nothing: when any time stamp is refused (MSFL_BAD_ARG) the cloud, host or device, is
+   left exactly as it was. */
 msfl_status msfl_deskew_cloud(msfl_handle* h, const msfl_preintegration* pre,
                               msfl_point* pts_io, int n, const double rot_odom_xyzw[4],
                               const double velocity[3], const double gravity[3], msfl_mem mem);

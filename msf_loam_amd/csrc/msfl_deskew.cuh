@@ -72,17 +72,29 @@ __global__ void __launch_bounds__(256) delta_qp_kernel(PreintView pv, const floa
   dp[3 * i] = o.p.x; dp[3 * i + 1] = o.p.y; dp[3 * i + 2] = o.p.z;
 }
 
+// The in-place passes below must be all-or-nothing (the reference CHECK-aborts before it has published anything): this
+// pre-pass validates every time stamp, and the in-place kernels do not touch the cloud when it has raised the flag.
+__global__ void __launch_bounds__(256) cloud_times_check_kernel(PreintView pv, const float4* __restrict__ pts, int n, int need_nonneg,
+                                                                 int* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float t = pts[i].w;
+  const double dt = (double)t;
+  const bool ok = pv.n >= 2 && dt >= pv.sum_dt[0] && dt <= pv.sum_dt[pv.n - 1] && (!need_nonneg || t >= 0.f);
+  if (!ok) *bad = 1;
+}
+
 struct DeskewConsts { quat rot_conj; d3 v, g; };   // pose_odom_scan2world.rotation().conjugate(), velocity, gravity
 
 // e = (dq * e + R_odom^-1 * (v dt - 0.5 g dt dt) + dp).cast<float>()     (laser_mapping.cc:198-204)
 __global__ void __launch_bounds__(256) deskew_cloud_kernel(PreintView pv, DeskewConsts c, float4* __restrict__ pts, int n,
-                                                            int* __restrict__ bad) {
+                                                            const int* __restrict__ bad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || *bad) return;                 // flag raised by cloud_times_check_kernel: leave the cloud untouched
   float4 e = pts[i];
   const double dt = (double)e.w;
   const DeltaQP o = delta_qp(pv, dt);
-  if (!o.ok) { *bad = 1; return; }
+  if (!o.ok) return;
   const d3 a = quat_rotate(o.q, mk3((double)e.x, (double)e.y, (double)e.z));
   const d3 m = mk3(c.v.x * dt - 0.5 * c.g.x * dt * dt, c.v.y * dt - 0.5 * c.g.y * dt * dt, c.v.z * dt - 0.5 * c.g.z * dt * dt);
   const d3 b = quat_rotate(c.rot_conj, m);
@@ -91,12 +103,12 @@ __global__ void __launch_bounds__(256) deskew_cloud_kernel(PreintView pv, Deskew
 }
 
 // p = dq.cast<float>() * p, Eigen's _transformVector in f32 (scan_undistortion.cc:14-16); CHECK_GE(time, 0) (:12)
-__global__ void __launch_bounds__(256) undistort_cloud_kernel(PreintView pv, float4* __restrict__ pts, int n, int* __restrict__ bad) {
+__global__ void __launch_bounds__(256) undistort_cloud_kernel(PreintView pv, float4* __restrict__ pts, int n, const int* __restrict__ bad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || *bad) return;
   float4 e = pts[i];
   const DeltaQP o = delta_qp(pv, (double)e.w);
-  if (!o.ok || !(e.w >= 0.f)) { *bad = 1; return; }
+  if (!o.ok || !(e.w >= 0.f)) return;
   const float qx = (float)o.q.x, qy = (float)o.q.y, qz = (float)o.q.z, qw = (float)o.q.w;
   float ux = qy * e.z - qz * e.y, uy = qz * e.x - qx * e.z, uz = qx * e.y - qy * e.x;
   ux += ux; uy += uy; uz += uz;

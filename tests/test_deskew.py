@@ -165,3 +165,27 @@ def test_gpu_delta_qp_feeds_the_deskew_matcher(gpu, oracle):
     assert s == rc == 0
     dt_, dr_ = synth.pose_error(pose_g, pose_o)
     assert dt_ < 1e-7 and dr_ < 1e-7
+
+
+@pytest.mark.gpu
+def test_gpu_in_place_passes_are_all_or_nothing_on_device_buffers(gpu):
+    """with MSFL_MEM_DEVICE a failing msfl_deskew_cloud / msfl_undistort_cloud must leave the caller's cloud
+    untouched (the reference CHECK-aborts before publishing anything), not half-modified."""
+    import ctypes as C
+    import torch
+    t, dq, dp = _preintegration()
+    pts = _cloud(5000)
+    pts[4321, 3] = 0.1001                                    # one time stamp outside the span, late in the cloud
+    pre, keep = gpu._preintegration(t, dq, dp)
+    d = torch.from_numpy(pts.copy()).cuda()
+    r, v, g = (np.ascontiguousarray(a, np.float64) for a in ([0, 0, 0, 1.0], [0.3, 0.1, 0.0], [0, 0, 9.81]))
+    s = gpu.lib.msfl_deskew_cloud(gpu.h, C.byref(pre), capi._vp(d), C.c_int(len(pts)), capi._vp(r), capi._vp(v), capi._vp(g), C.c_int(capi.MEM_DEVICE))
+    assert s == capi.BAD_ARG and np.array_equal(d.cpu().numpy(), pts)
+    s = gpu.lib.msfl_undistort_cloud(gpu.h, C.byref(pre), capi._vp(d), C.c_int(len(pts)), C.c_int(capi.MEM_DEVICE))
+    assert s == capi.BAD_ARG and np.array_equal(d.cpu().numpy(), pts)
+    pts[4321, 3] = 0.05                                       # valid now: the same buffer is transformed
+    d = torch.from_numpy(pts.copy()).cuda()
+    s = gpu.lib.msfl_deskew_cloud(gpu.h, C.byref(pre), capi._vp(d), C.c_int(len(pts)), capi._vp(r), capi._vp(v), capi._vp(g), C.c_int(capi.MEM_DEVICE))
+    assert s == 0
+    s2, host = gpu.deskew_cloud(t, dq, dp, pts, r, v, g)
+    assert s2 == 0 and np.array_equal(d.cpu().numpy(), host)
