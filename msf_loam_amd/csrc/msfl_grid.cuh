@@ -12,6 +12,10 @@
 // single point is the point itself, re-filtering an untouched cell is the identity: InsertScan is
 // therefore "append, stable-sort everything by key (old points first), one centroid per key run"
 // — one rocPRIM radix sort + two light kernels, no per-cell containers, no pointer chasing.
+// A map point keeps the key of the run it was created from (the reference keeps a point in the cell
+// container it was pushed into and does not re-derive the cell from the centroid's coordinates).
+// Cost per insert is O(map + scan) (one sort over everything); merging the sorted scan into the
+// sorted map and re-filtering only the runs that received points would make it O(scan).
 // GetSurroundedCloud marks cells through a binary search over the sorted unique cell keys.
 #pragma once
 #include <hip/hip_runtime.h>
