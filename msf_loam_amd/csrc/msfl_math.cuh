@@ -212,19 +212,20 @@ __device__ __forceinline__ void qr_step(double (&A)[5][3], double (&b)[5], int (
 #pragma unroll
   for (int i = K; i < 5; i++) vtv += v[i] * v[i];
   if (vtv > 0.0) {
+    const double tau = 2.0 / vtv;          // one division per reflector (Eigen applies H = I - tau v v^T the same way)
 #pragma unroll
     for (int j = K; j < 3; j++) {
       double s = 0.0;
 #pragma unroll
       for (int i = K; i < 5; i++) s += v[i] * A[i][j];
-      s = 2.0 * s / vtv;
+      s = s * tau;
 #pragma unroll
       for (int i = K; i < 5; i++) A[i][j] -= s * v[i];
     }
     double s = 0.0;
 #pragma unroll
     for (int i = K; i < 5; i++) s += v[i] * b[i];
-    s = 2.0 * s / vtv;
+    s = s * tau;
 #pragma unroll
     for (int i = K; i < 5; i++) b[i] -= s * v[i];
   }
