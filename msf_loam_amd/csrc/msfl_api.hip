@@ -126,6 +126,7 @@ struct msfl_handle_s {
   MapIndex map_c, map_s;
   int grid_cap_cells = 64 * 1024 * 1024;  // hard limit of the dense cell table (MSFL_GRID_CAP_CELLS)
   int h2d_chunk_scans = 512;              // MSFL_H2D_CHUNK_SCANS: scans per PCIe chunk of a host-buffer batch (>= 2 chunks to pipeline)
+  bool voxel_force_global = false;        // MSFL_VOXEL_GLOBAL=1: the batched voxel filter keeps the device-wide radix-sort form (A/B testing)
   bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)
 
   // scratch
@@ -461,6 +462,7 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
   if (const char* e = std::getenv("MSFL_GRID_CAP_CELLS")) { const int c = std::atoi(e); if (c >= 8 && c <= (1 << 28)) h->grid_cap_cells = c; }
   if (const char* e = std::getenv("MSFL_H2D_CHUNK_SCANS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_chunk_scans = c; }
   if (const char* e = std::getenv("MSFL_ODOM_BRUTE")) h->odom_force_brute = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MSFL_VOXEL_GLOBAL")) h->voxel_force_global = std::atoi(e) != 0;
   *out = h;
   return MSFL_OK;
 }

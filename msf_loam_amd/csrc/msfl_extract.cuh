@@ -799,6 +799,214 @@ __global__ void __launch_bounds__(256) voxel_batch_centroid_kernel(const float4*
   if (e == n) for (int cl = b + 1; cl <= n_clouds; cl++) out_off[cl] = m;
 }
 
+// ---- batched voxel filter, one workgroup per cloud, everything between the two reads of the points in LDS ----
+// The device-wide form above streams the batch through HBM about ten times (keys, four radix passes over 64-bit keys,
+// flags, scan, gather, centroids).  A cloud's points do not fit in LDS (a VLP-16 less-flat list is ~23 k points), but
+// its RUNS do: points arrive in ring / azimuth order, so consecutive points mostly fall into the same voxel, and a run of
+// consecutive same-voxel points is one 8-byte record {voxel, first point, length}.  Sorting the runs by voxel id with a
+// STABLE radix keeps them in arrival order inside a voxel, and summing a voxel's runs point by point reproduces
+// pcl::VoxelGrid's centroid accumulation (f32 sums in arrival order) bit for bit.
+//   phase 1 (global read 1)  every wavefront owns a contiguous slice of the cloud: absolute voxel coordinates
+//                            floor(p * inv_leaf), head flags against the previous point, run records into the
+//                            wavefront's own slot range (so run ids ascend with the arrival order), integer bounding box
+//   phase 2                  bounding box -> min_b / div_b (= pcl's, floor is monotone), coordinates -> voxel index
+//   phase 3                  LSD radix sort of the run ids by voxel index, 8 bits per pass, stable: per-wavefront
+//                            histograms, bin-major prefix, ballot-matched ranks inside a 64-run chunk
+//   phase 4                  voxel heads in the sorted order
+//   phase 5 (global read 2)  one thread per voxel: its runs in order, their points in order, centroid to the staging
+//                            area of the cloud (the clouds are compacted by voxel_batch_compact_kernel afterwards)
+// flags[b]: 0 ok, 1 / 2 / 3 = VoxelCloudDesc::bad, 4 = does not fit (too many runs or points, coordinates beyond
+// +-8191 voxels): the caller then runs the device-wide form for the whole batch.
+constexpr int kVoxWaves = 16;                       // 1024 threads
+constexpr int kVoxRunsPerWave = 768;                // run slots per wavefront
+constexpr int kVoxMaxRuns = kVoxWaves * kVoxRunsPerWave;     // 12 288 runs: 96 KB of records + 48 KB of order buffers
+constexpr int kVoxMaxPoints = 65535;                // the first point of a run is a 16-bit number
+
+__global__ void __launch_bounds__(1024) voxel_cloud_lds_kernel(VoxelBatchView v, float4* __restrict__ staging, int* __restrict__ m_out,
+                                                                int* __restrict__ flags) {
+  __shared__ unsigned long long s_run[kVoxMaxRuns];           // [coords 3 x 14 bits, later the voxel index : 42][first point : 16][length - 1 : 6]
+  __shared__ unsigned short s_ord[2][kVoxMaxRuns];
+  __shared__ unsigned short s_hist[kVoxWaves][256];
+  __shared__ int s_wcount[kVoxWaves];
+  __shared__ int s_bb[6];
+  __shared__ int s_flag, s_total, s_wsum[kVoxWaves];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cap = v.off[b + 1] - v.off[b];
+  const int n = v.count ? min(max(v.count[b], 0), cap) : cap;
+  if (tid == 0) { s_flag = 0; for (int a = 0; a < 3; a++) { s_bb[a] = INT32_MAX; s_bb[3 + a] = INT32_MIN; } }
+  __syncthreads();
+  if (n > kVoxMaxPoints) { if (tid == 0) { flags[b] = 4; m_out[b] = 0; } return; }
+  // ---- phase 1 ----
+  const int seg = ((n + kVoxWaves - 1) / kVoxWaves + 63) & ~63;       // points per wavefront, whole chunks
+  const int k0 = wave * seg, k1 = min(k0 + seg, n);
+  int n_runs = 0;                                                      // of this wavefront (uniform)
+  int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  int my_flag = 0;
+  for (int base = k0; base < k1; base += 64) {
+    const int k = base + lane;
+    const bool valid = k < k1;
+    int c0 = 0, c1 = 0, c2 = 0;
+    if (valid) {
+      const float4 p = vb_point(v, b, k);
+      const float f0 = floorf(p.x * v.inv_leaf), f1 = floorf(p.y * v.inv_leaf), f2 = floorf(p.z * v.inv_leaf);
+      if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) my_flag = max(my_flag, 3);
+      else if (!(fabsf(f0) < 8191.f && fabsf(f1) < 8191.f && fabsf(f2) < 8191.f)) my_flag = max(my_flag, 4);
+      c0 = (int)f0; c1 = (int)f1; c2 = (int)f2;
+      mn[0] = min(mn[0], c0); mn[1] = min(mn[1], c1); mn[2] = min(mn[2], c2);
+      mx[0] = max(mx[0], c0); mx[1] = max(mx[1], c1); mx[2] = max(mx[2], c2);
+    }
+    // a run never crosses a chunk: lane 0 always opens one
+    const int q0 = __shfl_up(c0, 1), q1 = __shfl_up(c1, 1), q2 = __shfl_up(c2, 1);
+    const bool head = valid && (lane == 0 || c0 != q0 || c1 != q1 || c2 != q2);
+    const unsigned long long heads = __ballot(head), live = __ballot(valid);
+    if (head) {
+      const unsigned long long above = heads & ~((2ull << lane) - 1ull);             // heads in higher lanes
+      const int end = above ? __ffsll((long long)above) - 1 : __popcll(live);
+      const int slot = n_runs + __popcll(heads & ((1ull << lane) - 1ull));
+      if (slot < kVoxRunsPerWave)
+        s_run[wave * kVoxRunsPerWave + slot] = ((unsigned long long)(unsigned)(c0 + 8192) << 50) | ((unsigned long long)(unsigned)(c1 + 8192) << 36) |
+                                               ((unsigned long long)(unsigned)(c2 + 8192) << 22) | ((unsigned long long)(unsigned)k << 6) |
+                                               (unsigned long long)(end - lane - 1);
+    }
+    n_runs += __popcll(heads);
+  }
+  if (n_runs > kVoxRunsPerWave) my_flag = max(my_flag, 4);
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn[a] = min(mn[a], __shfl_xor(mn[a], o)); mx[a] = max(mx[a], __shfl_xor(mx[a], o)); }
+  if (lane == 0) {
+    s_wcount[wave] = min(n_runs, kVoxRunsPerWave);
+    for (int a = 0; a < 3; a++) { atomicMin(&s_bb[a], mn[a]); atomicMax(&s_bb[3 + a], mx[a]); }
+  }
+  if (my_flag) atomicMax(&s_flag, my_flag);
+  __syncthreads();
+  // ---- phase 2 ----
+  int flag = s_flag;
+  const int mb0 = s_bb[0], mb1 = s_bb[1], mb2 = s_bb[2];
+  const long long d0 = (long long)s_bb[3] - mb0 + 1, d1 = (long long)s_bb[4] - mb1 + 1, d2 = (long long)s_bb[5] - mb2 + 1;
+  long long cells = 1;
+  if (n > 0 && flag == 0) {
+    cells = d0; if (cells > 0x7fffffffLL) flag = 1;
+    if (!flag) { cells *= d1; if (cells > 0x7fffffffLL) flag = 1; }
+    if (!flag) { cells *= d2; if (cells > 0x7fffffffLL) flag = 1; }        // pcl: "leaf size too small", the cloud is not filtered
+  }
+  if (flag != 0 || n == 0) { if (tid == 0) { flags[b] = flag; m_out[b] = 0; } return; }
+  int wbase = 0, E = 0;                                    // runs before this wavefront's, all runs
+  for (int w = 0; w < kVoxWaves; w++) { const int c = s_wcount[w]; if (w < wave) wbase += c; E += c; }
+  for (int e = lane; e < s_wcount[wave]; e += 64) {
+    const int id = wave * kVoxRunsPerWave + e;
+    const unsigned long long r = s_run[id];
+    const long long i0 = (long long)((int)(r >> 50) & 0x3fff) - 8192 - mb0, i1 = (long long)((int)(r >> 36) & 0x3fff) - 8192 - mb1,
+                    i2 = (long long)((int)(r >> 22) & 0x3fff) - 8192 - mb2;
+    const unsigned long long cell = (unsigned long long)(i0 + i1 * d0 + i2 * d0 * d1);
+    s_run[id] = (cell << 22) | (r & 0x3fffffull);
+    s_ord[0][wbase + e] = (unsigned short)id;              // run ids in arrival order
+  }
+  int nbits = 1;
+  while ((1ll << nbits) < cells) nbits++;
+  __syncthreads();
+  // ---- phase 3: stable LSD radix over the voxel index ----
+  const int segE = ((E + kVoxWaves - 1) / kVoxWaves + 63) & ~63;
+  const int e0 = min(wave * segE, E), e1 = min(e0 + segE, E);
+  int cur = 0;
+  for (int shift = 0; shift < nbits; shift += 8) {
+    for (int d = lane; d < 256; d += 64) s_hist[wave][d] = 0;
+    // (no barrier: a wavefront only touches its own histogram row until the prefix)
+    for (int base = e0; base < e1; base += 64) {
+      const int pos = base + lane;
+      const bool valid = pos < e1;
+      const unsigned dg = valid ? (unsigned)((s_run[s_ord[cur][pos]] >> (22 + shift)) & 0xffu) : 0x100u;
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) { const unsigned long long m = __ballot((dg >> bit) & 1u); peers &= ((dg >> bit) & 1u) ? m : ~m; }
+      if (valid && (peers & ((1ull << lane) - 1ull)) == 0) s_hist[wave][dg] += (unsigned short)__popcll(peers);      // the group's first lane
+    }
+    __syncthreads();
+    {
+      // exclusive prefix over (digit major, wavefront minor): thread t owns entries 4t .. 4t+3 of that order
+      unsigned short c[4]; int sum = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const int e = 4 * tid + q; c[q] = s_hist[e & 15][e >> 4]; sum += c[q]; }
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+      if (lane == 63) s_wsum[wave] = incl;
+      __syncthreads();
+      int run = incl - sum;
+      for (int w = 0; w < wave; w++) run += s_wsum[w];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const int e = 4 * tid + q; s_hist[e & 15][e >> 4] = (unsigned short)run; run += c[q]; }
+    }
+    __syncthreads();
+    for (int base = e0; base < e1; base += 64) {
+      const int pos = base + lane;
+      const bool valid = pos < e1;
+      const unsigned short id = valid ? s_ord[cur][pos] : (unsigned short)0;
+      const unsigned dg = valid ? (unsigned)((s_run[id] >> (22 + shift)) & 0xffu) : 0x100u;
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) { const unsigned long long m = __ballot((dg >> bit) & 1u); peers &= ((dg >> bit) & 1u) ? m : ~m; }
+      if (valid) {
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        const int at = s_hist[wave][dg];
+        s_ord[cur ^ 1][at + rank] = id;
+        if (rank == 0) s_hist[wave][dg] = (unsigned short)(at + __popcll(peers));
+      }
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  // ---- phase 4: voxel heads (positions in the sorted order) into the other order buffer ----
+  unsigned short* heads_at = s_ord[cur ^ 1];
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  for (int base = 0; base < E; base += 1024) {
+    const int pos = base + tid;
+    bool head = false;
+    if (pos < E) head = pos == 0 || (s_run[s_ord[cur][pos]] >> 22) != (s_run[s_ord[cur][pos - 1]] >> 22);
+    const unsigned long long hm = __ballot(head);
+    if (lane == 0) s_wsum[wave] = __popcll(hm);
+    __syncthreads();
+    int at = s_total + __popcll(hm & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++) at += s_wsum[w];
+    if (head) heads_at[at] = (unsigned short)pos;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < kVoxWaves; w++) t += s_wsum[w]; s_total += t; }
+    __syncthreads();
+  }
+  const int m = s_total;
+  // ---- phase 5: one thread per voxel ----
+  float4* out = staging + v.off[b];
+  for (int r = tid; r < m; r += 1024) {
+    const int j0 = heads_at[r], j1 = (r + 1 < m) ? (int)heads_at[r + 1] : E;
+    float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
+    int cnt = 0;
+    for (int j = j0; j < j1; j++) {
+      const unsigned long long rec = s_run[s_ord[cur][j]];
+      const int k = (int)((rec >> 6) & 0xffffu), len = (int)(rec & 0x3fu) + 1;
+      for (int e = 0; e < len; e++) {
+        const float4 p = vb_point(v, b, k + e);
+        sx += p.x; sy += p.y; sz += p.z; st += p.w;               // CentroidPoint accumulators (f32), arrival order
+      }
+      cnt += len;
+    }
+    const float c = (float)cnt;
+    out[r] = make_float4(sx / c, sy / c, sz / c, st / c);
+  }
+  if (tid == 0) { flags[b] = 0; m_out[b] = m; }
+}
+
+// staging (cloud b's centroids at off[b]) -> the clouds back to back: out[out_off[b] + r]
+__global__ void __launch_bounds__(256) voxel_batch_compact_kernel(const float4* __restrict__ staging, const int* __restrict__ off,
+                                                                   const int* __restrict__ out_off, int n_clouds, float4* __restrict__ out) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= out_off[n_clouds]) return;
+  const int b = find_scan_off_wave(out_off, n_clouds, o);
+  out[o] = staging[off[b] + (o - out_off[b])];
+}
+
 // exclusive scan of the per-cloud voxel counts (B is small: one workgroup, serial per 1024-chunk carry)
 __global__ void __launch_bounds__(1024) voxel_batch_offsets_kernel(const int* __restrict__ cnt, int n, int* __restrict__ off) {
   __shared__ int s_part[16];

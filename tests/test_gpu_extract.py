@@ -188,3 +188,47 @@ def test_voxel_filters_refuse_non_finite_points(gpu):
         assert e.value.status == capi.BAD_ARG
     out, off = gpu.voxel_downsample_batch(np.concatenate([pts, pts]), np.array([0, 500, 1000], np.int32), 0.4)
     assert off[1] == off[2] - off[1] == len(gpu.voxel_downsample(pts, 0.4))
+
+
+def test_batched_voxel_filter_lds_form_and_its_fallbacks(oracle, monkeypatch):
+    """The batched filter sorts each cloud's RUNS in LDS (one workgroup per cloud) and falls back to the device-wide radix
+    sort for the whole batch when a cloud does not fit (more than 65 535 points, too many runs, coordinates beyond +-8191
+    voxels).  Both forms must agree with the oracle bit for bit: real feature lists (long runs), uniformly random points
+    (every run has length 1), a cloud above each limit, and duplicated points."""
+    from msf_loam_amd import capi
+    rng = np.random.default_rng(23)
+    w, _, _ = common.small_world()
+    scans = [synth.make_scan(w, p, 900 + i) for i, p in enumerate(synth.random_poses(4, 43))]
+    lists = []
+    for p, r in scans:
+        f = oracle.extract_features(p, r)
+        lists.append(f["full"][f["less_flat"]])
+        lists.append(f["full"][f["less_sharp"]])
+    rand = np.zeros((9000, 4), np.float32); rand[:, :3] = rng.uniform(-20, 20, (9000, 3)); rand[:, 3] = rng.uniform(0, 0.1, 9000)
+    dup = np.repeat(rand[:300], 7, axis=0)                                  # runs of 7 identical points
+    line = np.zeros((3000, 4), np.float32); line[:, 0] = np.linspace(-50, 50, 3000)   # one long polyline: runs of ~12
+    base = lists + [rand, dup, line, np.zeros((0, 4), np.float32), rand[:1]]
+
+    def check(h, clouds, leaf):
+        off = np.cumsum([0] + [len(c) for c in clouds]).astype(np.int32)
+        out, out_off = h.voxel_downsample_batch(np.concatenate(clouds), off, leaf)
+        for b, c in enumerate(clouds):
+            ref = oracle.voxel_grid(c, leaf) if len(c) else np.zeros((0, 4), np.float32)
+            assert np.array_equal(out[out_off[b]:out_off[b + 1]], ref), (leaf, b, len(c))
+        return out, out_off
+
+    h = capi.Handle(0)
+    monkeypatch.setenv("MSFL_VOXEL_GLOBAL", "1")
+    hg = capi.Handle(0)
+    try:
+        for leaf in (0.2, 0.4, 1.5):
+            a = check(h, base, leaf)
+            g = check(hg, base, leaf)
+            assert np.array_equal(a[0], g[0]) and np.array_equal(a[1], g[1])
+        big = np.zeros((70000, 4), np.float32); big[:, :3] = rng.uniform(-30, 30, (70000, 3))     # > 65 535 points
+        many_runs = np.zeros((30000, 4), np.float32); many_runs[:, :3] = rng.uniform(-30, 30, (30000, 3))   # 30 000 runs of length 1
+        far = rand.copy(); far[0, 0] = 5000.0                                                      # 25 000 voxels from the rest at 0.2 m
+        for extra, leaf in ((big, 0.4), (many_runs, 0.4), (far, 0.2)):
+            check(h, base[:3] + [extra] + base[3:6], leaf)
+    finally:
+        h.close(); hg.close()
