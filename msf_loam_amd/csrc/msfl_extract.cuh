@@ -816,14 +816,21 @@ __global__ void __launch_bounds__(256) voxel_batch_centroid_kernel(const float4*
 //   phase 5 (global read 2)  one thread per voxel: its runs in order, their points in order, centroid to the staging
 //                            area of the cloud (the clouds are compacted by voxel_batch_compact_kernel afterwards)
 // flags[b]: 0 ok, 1 / 2 / 3 = VoxelCloudDesc::bad, 4 = does not fit (too many runs or points, coordinates beyond
-// +-8191 voxels): the caller then runs the device-wide form for the whole batch.
-constexpr int kVoxWaves = 16;                       // 1024 threads
-constexpr int kVoxRunsPerWave = 768;                // run slots per wavefront
-constexpr int kVoxMaxRuns = kVoxWaves * kVoxRunsPerWave;     // 12 288 runs: 96 KB of records + 48 KB of order buffers
+// +-8191 voxels): the caller then runs the device-wide form for the whole batch; 5 = escalated by the small instantiation.
+// Two instantiations: <16, 768> (1024 threads, 12 288 runs: 96 KB of records + 48 KB of order buffers, one workgroup
+// per CU) for clouds like a less-flat list, <4, 512> (256 threads, 2 048 runs, 26 KB: six workgroups per CU) when every
+// cloud of the batch has at most kVoxSmallPoints points (corner lists).
+#ifndef MSFL_VOX_EXP
+#define MSFL_VOX_EXP 0       // timing experiments only (stop after phase 1 / 3 / 4)
+#endif
 constexpr int kVoxMaxPoints = 65535;                // the first point of a run is a 16-bit number
+constexpr int kVoxSmallPoints = 4096;
 
-__global__ void __launch_bounds__(1024) voxel_cloud_lds_kernel(VoxelBatchView v, float4* __restrict__ staging, int* __restrict__ m_out,
-                                                                int* __restrict__ flags) {
+template <int kVoxWaves, int kVoxRunsPerWave>
+__global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBatchView v, float4* __restrict__ staging, int* __restrict__ m_out,
+                                                                          int* __restrict__ flags, int only_escalated) {
+  constexpr int kVoxMaxRuns = kVoxWaves * kVoxRunsPerWave;
+  constexpr int kThreads = 64 * kVoxWaves;
   __shared__ unsigned long long s_run[kVoxMaxRuns];           // [coords 3 x 14 bits, later the voxel index : 42][first point : 16][length - 1 : 6]
   __shared__ unsigned short s_ord[2][kVoxMaxRuns];
   __shared__ unsigned short s_hist[kVoxWaves][256];
@@ -834,44 +841,59 @@ __global__ void __launch_bounds__(1024) voxel_cloud_lds_kernel(VoxelBatchView v,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cap = v.off[b + 1] - v.off[b];
   const int n = v.count ? min(max(v.count[b], 0), cap) : cap;
+  // the small instantiation runs first and ESCALATES (flag 5) what it cannot hold; the large one then only serves those
+  constexpr bool kSmall = kVoxWaves < 16;
+  if (only_escalated && flags[b] != 5) return;
   if (tid == 0) { s_flag = 0; for (int a = 0; a < 3; a++) { s_bb[a] = INT32_MAX; s_bb[3 + a] = INT32_MIN; } }
   __syncthreads();
-  if (n > kVoxMaxPoints) { if (tid == 0) { flags[b] = 4; m_out[b] = 0; } return; }
+  if (n > (kSmall ? kVoxSmallPoints : kVoxMaxPoints)) { if (tid == 0) { flags[b] = kSmall ? 5 : 4; m_out[b] = 0; } return; }
   // ---- phase 1 ----
   const int seg = ((n + kVoxWaves - 1) / kVoxWaves + 63) & ~63;       // points per wavefront, whole chunks
   const int k0 = wave * seg, k1 = min(k0 + seg, n);
   int n_runs = 0;                                                      // of this wavefront (uniform)
   int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
   int my_flag = 0;
-  for (int base = k0; base < k1; base += 64) {
-    const int k = base + lane;
-    const bool valid = k < k1;
-    int c0 = 0, c1 = 0, c2 = 0;
-    if (valid) {
-      const float4 p = vb_point(v, b, k);
-      const float f0 = floorf(p.x * v.inv_leaf), f1 = floorf(p.y * v.inv_leaf), f2 = floorf(p.z * v.inv_leaf);
-      if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) my_flag = max(my_flag, 3);
-      else if (!(fabsf(f0) < 8191.f && fabsf(f1) < 8191.f && fabsf(f2) < 8191.f)) my_flag = max(my_flag, 4);
-      c0 = (int)f0; c1 = (int)f1; c2 = (int)f2;
-      mn[0] = min(mn[0], c0); mn[1] = min(mn[1], c1); mn[2] = min(mn[2], c2);
-      mx[0] = max(mx[0], c0); mx[1] = max(mx[1], c1); mx[2] = max(mx[2], c2);
+  constexpr int kU = 4;                                                // chunks whose loads are in flight together
+  for (int base0 = k0; base0 < k1; base0 += 64 * kU) {
+    float4 pp[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const int k = base0 + 64 * u + lane;
+      pp[u] = vb_point(v, b, min(k, n - 1));                             // clamped: unconditional loads, all issued before the first use
     }
-    // a run never crosses a chunk: lane 0 always opens one
-    const int q0 = __shfl_up(c0, 1), q1 = __shfl_up(c1, 1), q2 = __shfl_up(c2, 1);
-    const bool head = valid && (lane == 0 || c0 != q0 || c1 != q1 || c2 != q2);
-    const unsigned long long heads = __ballot(head), live = __ballot(valid);
-    if (head) {
-      const unsigned long long above = heads & ~((2ull << lane) - 1ull);             // heads in higher lanes
-      const int end = above ? __ffsll((long long)above) - 1 : __popcll(live);
-      const int slot = n_runs + __popcll(heads & ((1ull << lane) - 1ull));
-      if (slot < kVoxRunsPerWave)
-        s_run[wave * kVoxRunsPerWave + slot] = ((unsigned long long)(unsigned)(c0 + 8192) << 50) | ((unsigned long long)(unsigned)(c1 + 8192) << 36) |
-                                               ((unsigned long long)(unsigned)(c2 + 8192) << 22) | ((unsigned long long)(unsigned)k << 6) |
-                                               (unsigned long long)(end - lane - 1);
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const int base = base0 + 64 * u;
+      if (base >= k1) break;
+      const int k = base + lane;
+      const bool valid = k < k1;
+      int c0 = 0, c1 = 0, c2 = 0;
+      if (valid) {
+        const float4 p = pp[u];
+        const float f0 = floorf(p.x * v.inv_leaf), f1 = floorf(p.y * v.inv_leaf), f2 = floorf(p.z * v.inv_leaf);
+        if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) my_flag = max(my_flag, 3);
+        else if (!(fabsf(f0) < 8191.f && fabsf(f1) < 8191.f && fabsf(f2) < 8191.f)) my_flag = max(my_flag, 4);
+        c0 = (int)f0; c1 = (int)f1; c2 = (int)f2;
+        mn[0] = min(mn[0], c0); mn[1] = min(mn[1], c1); mn[2] = min(mn[2], c2);
+        mx[0] = max(mx[0], c0); mx[1] = max(mx[1], c1); mx[2] = max(mx[2], c2);
+      }
+      // a run never crosses a chunk: lane 0 always opens one
+      const int q0 = __shfl_up(c0, 1), q1 = __shfl_up(c1, 1), q2 = __shfl_up(c2, 1);
+      const bool head = valid && (lane == 0 || c0 != q0 || c1 != q1 || c2 != q2);
+      const unsigned long long heads = __ballot(head), live = __ballot(valid);
+      if (head) {
+        const unsigned long long above = heads & ~((2ull << lane) - 1ull);             // heads in higher lanes
+        const int end = above ? __ffsll((long long)above) - 1 : __popcll(live);
+        const int slot = n_runs + __popcll(heads & ((1ull << lane) - 1ull));
+        if (slot < kVoxRunsPerWave)
+          s_run[wave * kVoxRunsPerWave + slot] = ((unsigned long long)(unsigned)(c0 + 8192) << 50) | ((unsigned long long)(unsigned)(c1 + 8192) << 36) |
+                                                 ((unsigned long long)(unsigned)(c2 + 8192) << 22) | ((unsigned long long)(unsigned)k << 6) |
+                                                 (unsigned long long)(end - lane - 1);
+      }
+      n_runs += __popcll(heads);
     }
-    n_runs += __popcll(heads);
   }
-  if (n_runs > kVoxRunsPerWave) my_flag = max(my_flag, 4);
+  if (n_runs > kVoxRunsPerWave) my_flag = max(my_flag, kSmall ? 5 : 4);
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -882,6 +904,9 @@ __global__ void __launch_bounds__(1024) voxel_cloud_lds_kernel(VoxelBatchView v,
   }
   if (my_flag) atomicMax(&s_flag, my_flag);
   __syncthreads();
+#if MSFL_VOX_EXP == 1
+  if (tid == 0) { flags[b] = 0; m_out[b] = 0; } return;
+#endif
   // ---- phase 2 ----
   int flag = s_flag;
   const int mb0 = s_bb[0], mb1 = s_bb[1], mb2 = s_bb[2];
@@ -928,7 +953,7 @@ __global__ void __launch_bounds__(1024) voxel_cloud_lds_kernel(VoxelBatchView v,
       // exclusive prefix over (digit major, wavefront minor): thread t owns entries 4t .. 4t+3 of that order
       unsigned short c[4]; int sum = 0;
 #pragma unroll
-      for (int q = 0; q < 4; q++) { const int e = 4 * tid + q; c[q] = s_hist[e & 15][e >> 4]; sum += c[q]; }
+      for (int q = 0; q < 4; q++) { const int e = 4 * tid + q; c[q] = s_hist[e % kVoxWaves][e / kVoxWaves]; sum += c[q]; }
       int incl = sum;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
@@ -937,7 +962,7 @@ __global__ void __launch_bounds__(1024) voxel_cloud_lds_kernel(VoxelBatchView v,
       int run = incl - sum;
       for (int w = 0; w < wave; w++) run += s_wsum[w];
 #pragma unroll
-      for (int q = 0; q < 4; q++) { const int e = 4 * tid + q; s_hist[e & 15][e >> 4] = (unsigned short)run; run += c[q]; }
+      for (int q = 0; q < 4; q++) { const int e = 4 * tid + q; s_hist[e % kVoxWaves][e / kVoxWaves] = (unsigned short)run; run += c[q]; }
     }
     __syncthreads();
     for (int base = e0; base < e1; base += 64) {
@@ -958,11 +983,14 @@ __global__ void __launch_bounds__(1024) voxel_cloud_lds_kernel(VoxelBatchView v,
     cur ^= 1;
     __syncthreads();
   }
+#if MSFL_VOX_EXP == 2
+  if (tid == 0) { flags[b] = 0; m_out[b] = 0; } return;
+#endif
   // ---- phase 4: voxel heads (positions in the sorted order) into the other order buffer ----
   unsigned short* heads_at = s_ord[cur ^ 1];
   if (tid == 0) s_total = 0;
   __syncthreads();
-  for (int base = 0; base < E; base += 1024) {
+  for (int base = 0; base < E; base += kThreads) {
     const int pos = base + tid;
     bool head = false;
     if (pos < E) head = pos == 0 || (s_run[s_ord[cur][pos]] >> 22) != (s_run[s_ord[cur][pos - 1]] >> 22);
@@ -979,21 +1007,67 @@ __global__ void __launch_bounds__(1024) voxel_cloud_lds_kernel(VoxelBatchView v,
   const int m = s_total;
   // ---- phase 5: one thread per voxel ----
   float4* out = staging + v.off[b];
-  for (int r = tid; r < m; r += 1024) {
+#if MSFL_VOX_EXP == 3
+  if (tid == 0) { flags[b] = 0; m_out[b] = 0; } return;
+#endif
+  // Small voxels: one thread each.  A voxel close to the sensor can hold hundreds of points (a 0.4 m cube on the ground
+  // two metres out takes ~60 points of every ring that crosses it): a single thread would chain that many dependent loads
+  // while its workgroup, the only one on the CU, waits.  Voxels with more than kBigVoxel points are therefore collected
+  // (s_hist is free now) and summed by a whole wavefront each: one coalesced load per run, then the same sequential
+  // f32 additions on every lane through broadcasts.
+  constexpr int kBigVoxel = 24;
+  unsigned short* big_list = &s_hist[0][0];                 // up to kVoxWaves * 256 entries
+  __syncthreads();                                           // every thread has read m = s_total
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  for (int r = tid; r < m; r += kThreads) {
     const int j0 = heads_at[r], j1 = (r + 1 < m) ? (int)heads_at[r + 1] : E;
+    int total = 0;
+    for (int j = j0; j < j1; j++) total += (int)(s_run[s_ord[cur][j]] & 0x3fu) + 1;
+    if (total > kBigVoxel) {
+      const int at = atomicAdd(&s_total, 1);
+      if (at < kVoxWaves * 256) { big_list[at] = (unsigned short)r; continue; }        // list full: summed by this thread after all
+    }
     float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
-    int cnt = 0;
     for (int j = j0; j < j1; j++) {
       const unsigned long long rec = s_run[s_ord[cur][j]];
       const int k = (int)((rec >> 6) & 0xffffu), len = (int)(rec & 0x3fu) + 1;
-      for (int e = 0; e < len; e++) {
-        const float4 p = vb_point(v, b, k + e);
-        sx += p.x; sy += p.y; sz += p.z; st += p.w;               // CentroidPoint accumulators (f32), arrival order
+      for (int e = 0; e < len; e += 4) {                                // four loads in flight, added in arrival order
+        const float4 p0 = vb_point(v, b, k + e), p1 = vb_point(v, b, k + min(e + 1, len - 1)), p2 = vb_point(v, b, k + min(e + 2, len - 1)),
+                     p3 = vb_point(v, b, k + min(e + 3, len - 1));
+        sx += p0.x; sy += p0.y; sz += p0.z; st += p0.w;               // CentroidPoint accumulators (f32), arrival order
+        if (e + 1 < len) { sx += p1.x; sy += p1.y; sz += p1.z; st += p1.w; }
+        if (e + 2 < len) { sx += p2.x; sy += p2.y; sz += p2.z; st += p2.w; }
+        if (e + 3 < len) { sx += p3.x; sy += p3.y; sz += p3.z; st += p3.w; }
       }
-      cnt += len;
     }
-    const float c = (float)cnt;
+    const float c = (float)total;
     out[r] = make_float4(sx / c, sy / c, sz / c, st / c);
+  }
+  __syncthreads();
+  const int n_big = min(s_total, kVoxWaves * 256);
+  for (int q = wave; q < n_big; q += kVoxWaves) {
+    const int r = big_list[q];
+    const int j0 = heads_at[r], j1 = (r + 1 < m) ? (int)heads_at[r + 1] : E;
+    float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
+    int total = 0;
+    // software pipeline over the runs: the next run's points are loading while this one is summed
+    unsigned long long rec = s_run[s_ord[cur][j0]];
+    int k = (int)((rec >> 6) & 0xffffu), len = (int)(rec & 0x3fu) + 1;
+    float4 p = vb_point(v, b, k + min(lane, len - 1));
+    for (int j = j0; j < j1; j++) {
+      const float4 pc = p; const int lc = len;
+      if (j + 1 < j1) {
+        rec = s_run[s_ord[cur][j + 1]];
+        k = (int)((rec >> 6) & 0xffffu); len = (int)(rec & 0x3fu) + 1;
+        p = vb_point(v, b, k + min(lane, len - 1));
+      }
+      for (int e = 0; e < lc; e++) {
+        sx += __shfl(pc.x, e); sy += __shfl(pc.y, e); sz += __shfl(pc.z, e); st += __shfl(pc.w, e);
+      }
+      total += lc;
+    }
+    if (lane == 0) { const float c = (float)total; out[r] = make_float4(sx / c, sy / c, sz / c, st / c); }
   }
   if (tid == 0) { flags[b] = 0; m_out[b] = m; }
 }
