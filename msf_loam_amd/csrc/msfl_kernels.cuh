@@ -401,7 +401,7 @@ __device__ __forceinline__ FitOut plane_fit(const float4 (&nb)[5], double tol) {
     c = c + mk3(A[j][0], A[j][1], A[j][2]);
   }
   c = mk3(c.x / 5.0, c.y / 5.0, c.z / 5.0);
-  const d3 n = normalized(lstsq5x3(A, b));   // note: lstsq5x3 overwrites A, b
+  const d3 n = normalized_rsq(lstsq5x3(A, b));   // note: lstsq5x3 overwrites A, b
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 5; j++) {
@@ -634,25 +634,6 @@ __device__ __forceinline__ void acc_row_w(double (&acc)[kAcc], const double (&j)
   for (int p2 = 0; p2 < 6; p2++)
 #pragma unroll
     for (int q = p2; q < 6; q++) { acc[n] = __builtin_fma(jw[p2], j[q], acc[n]); n++; }
-}
-
-// 1 / x for x in a benign range (no scaling / fix-up steps of the IEEE division sequence): v_rcp_f64 + two Newton
-// steps, within an ulp or two of the correctly rounded quotient
-__device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  double e = __builtin_fma(-x, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  e = __builtin_fma(-x, y, 1.0);
-  return __builtin_fma(y, e, y);
-}
-// 1 / sqrt(x), x > 0 and far from the denormal range: v_rsq_f64 + two Newton steps
-__device__ __forceinline__ double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  const double hx = 0.5 * x;
-  double e = __builtin_fma(-hx * y, y, 0.5);
-  y = __builtin_fma(y, e, y);
-  e = __builtin_fma(-hx * y, y, 0.5);
-  return __builtin_fma(y, e, y);
 }
 
 // HuberLoss(a) on s = |r|^2 given |r|: rho0 = rho(s), w = rho'(s) (Ceres loss_function.cc; the Corrector's

@@ -26,11 +26,38 @@ __device__ __forceinline__ double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ d3 cross(d3 a, d3 b) {
   return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// the same through one reciprocal square root (within an ulp or two per component): plane fit only
+__device__ __forceinline__ d3 normalized_rsq(d3 v);
 // Eigen 3.3 normalized(): guarded against the zero vector
 __device__ __forceinline__ d3 normalized(d3 v) {
   const double z = dot(v, v);
   if (z > 0.0) { const double s = sqrt(z); return mk3(v.x / s, v.y / s, v.z / s); }
   return v;
+}
+
+// 1 / x for x in a benign range (no scaling / fix-up steps of the IEEE division sequence): v_rcp_f64 + two Newton
+// steps, within an ulp or two of the correctly rounded quotient
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+// 1 / sqrt(x), x > 0 and far from the denormal range: v_rsq_f64 + two Newton steps
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  double e = __builtin_fma(-hx * y, y, 0.5);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-hx * y, y, 0.5);
+  return __builtin_fma(y, e, y);
+}
+
+__device__ __forceinline__ d3 normalized_rsq(d3 v) {
+  const double z = dot(v, v);
+  if (z > 1e-280 && z < 1e280) { const double s = fast_rsqrt(z); return mk3(v.x * s, v.y * s, v.z * s); }
+  return normalized(v);
 }
 
 struct quat { double x, y, z, w; };
@@ -247,10 +274,10 @@ __device__ __forceinline__ d3 lstsq5x3(double (&A)[5][3], double (&b)[5]) {
   const bool k0 = fabs(diag[0]) > thresh, k1 = fabs(diag[1]) > thresh, k2 = fabs(diag[2]) > thresh;
   const int rank = (int)k0 + (int)k1 + (int)k2;
   double y0 = 0, y1 = 0, y2 = 0;
-  if (rank == 3) {
-    y2 = b[2] / A[2][2];
-    y1 = (b[1] - A[1][2] * y2) / A[1][1];
-    y0 = (b[0] - A[0][1] * y1 - A[0][2] * y2) / A[0][0];
+  if (rank == 3) {                             // the generic case: reciprocals (v_rcp_f64 + two Newton steps) instead of three IEEE divisions
+    y2 = b[2] * fast_rcp(A[2][2]);
+    y1 = (b[1] - A[1][2] * y2) * fast_rcp(A[1][1]);
+    y0 = (b[0] - A[0][1] * y1 - A[0][2] * y2) * fast_rcp(A[0][0]);
   } else if (rank == 2) {
     y1 = b[1] / A[1][1];
     y0 = (b[0] - A[0][1] * y1) / A[0][0];
