@@ -627,49 +627,6 @@ __global__ void __launch_bounds__(256) extract_compact_kernel(ExtractView v, con
 // ---------------------------------------------------------------------------------------------
 // pcl::VoxelGrid centroid filter (laser_mapping.cc:264-270) — caller-side helper, SURVEY.md §8f N2
 // ---------------------------------------------------------------------------------------------
-struct VoxelDesc { float inv_leaf; int min_b[3]; int div_b[3]; };
-
-// *bad |= 1 when a point is not finite: pcl::VoxelGrid drops such points (the reference never feeds it one:
-// RemoveInvalidPointsFromCloud, msf_loam_node.cc:85-111); here the call is refused (MSFL_BAD_ARG) instead of
-// silently averaging NaN into a centroid
-__global__ void __launch_bounds__(256) voxel_key_kernel(const float4* __restrict__ pts, int n, VoxelDesc d,
-                                                         unsigned long long* __restrict__ keys, int* __restrict__ bad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
-  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) atomicOr(bad, 1);
-  const int i0 = (int)(floorf(p.x * d.inv_leaf) - (float)d.min_b[0]);
-  const int i1 = (int)(floorf(p.y * d.inv_leaf) - (float)d.min_b[1]);
-  const int i2 = (int)(floorf(p.z * d.inv_leaf) - (float)d.min_b[2]);
-  const unsigned long long cell = (unsigned long long)((long long)i0 + (long long)i1 * d.div_b[0] +
-                                                       (long long)i2 * d.div_b[0] * (long long)d.div_b[1]);
-  keys[i] = (cell << 32) | (unsigned int)i;     // sort by (voxel, point index): stable order inside a voxel
-}
-
-__global__ void __launch_bounds__(256) voxel_flag_kernel(const unsigned long long* __restrict__ keys, int n, int* __restrict__ flag) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  flag[i] = (i == 0 || (keys[i] >> 32) != (keys[i - 1] >> 32)) ? 1 : 0;
-}
-
-// pos[i] = inclusive scan of flag; one thread per voxel head accumulates its run sequentially in f32
-// (pcl CentroidPoint accumulators) and writes the centroid.
-__global__ void __launch_bounds__(256) voxel_centroid_kernel(const float4* __restrict__ pts, const unsigned long long* __restrict__ keys,
-                                                              const int* __restrict__ flag, const int* __restrict__ pos, int n,
-                                                              float4* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !flag[i]) return;
-  const unsigned long long cell = keys[i] >> 32;
-  float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
-  int j = i;
-  for (; j < n && (keys[j] >> 32) == cell; j++) {
-    const float4 p = pts[(unsigned int)keys[j]];
-    sx += p.x; sy += p.y; sz += p.z; st += p.w;
-  }
-  const float c = (float)(j - i);
-  out[pos[i] - 1] = make_float4(sx / c, sy / c, sz / c, st / c);
-}
-
 // ---- batched voxel filter: B clouds in one pass (pcl::VoxelGrid per cloud, laser_mapping.cc:264-270) ----
 // Cloud b = count[b] points pts[off[b] + (idx ? idx[off[b] + k] : k)], k < count[b]: the index form
 // reads feature lists straight out of the extraction's output (no gather pass).  Per-cloud bounding
@@ -703,7 +660,7 @@ __global__ void __launch_bounds__(256) voxel_batch_desc_kernel(VoxelBatchView v,
       mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
       mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
     } else {
-      s_nonfinite = 1;                        // refused below: see voxel_key_kernel
+      s_nonfinite = 1;                        // refused below: pcl::VoxelGrid would drop the point, the reference never feeds it one
     }
   }
 #pragma unroll
