@@ -1,13 +1,12 @@
 // msfl_extract.cuh — stage A: per-scan edge/plane feature extraction on gfx950.
 //
-// Replaces RealHandleLaserCloudMessage (msf_loam_node.cc:160-378).  Four kernels per batch:
+// Replaces RealHandleLaserCloudMessage (msf_loam_node.cc:160-378).  Four kernels per batch (round 2: the sector sort is gone):
 //   extract_prepare_kernel    one 1024-thread workgroup per scan: invalid-point removal (:85-111),
 //                             relative time (:128-156), stable split into rings + concat (:188-195)
 //   extract_curvature_kernel  one thread per point: 11-tap curvature (:213-240) + neighbour-gap flags
-//   extract_sort_kernel       one wavefront per (scan, ring, sector): LDS bitonic sort of 64-bit
-//                             (curvature, index) keys (:263-267)
 //   extract_pick_kernel       one wavefront per (scan, ring): the serial sharp / less-sharp / flat pick
-//                             with neighbour suppression on LDS bitmasks (:270-344)
+//                             (:263-344) as repeated wave-wide arg-max / arg-min over the sector's
+//                             (curvature, index) keys held in registers, neighbour suppression on LDS bitmasks
 //   extract_compact_kernel    per scan: order the per-ring lists into the reference's push order,
 //                             apply the lidar->imu extrinsic (:367-371)
 // All index outputs are bit-exact w.r.t. the CPU oracle; the unstable std::sort tie order of the
@@ -22,7 +21,6 @@ namespace msfl {
 
 constexpr int kMaxRings = 128;          // kMaxScanNum, msf_loam_node.cc:79
 constexpr int kRingCapacity = 8192;     // points per ring handled by the LDS bitmasks
-constexpr int kSortLds = 512;           // sector sizes up to this sort in LDS, larger ones in global scratch
 
 struct ExtractParams {
   double min_range;
@@ -55,7 +53,6 @@ struct ExtractView {
   int* ring_tab;               // n_scans x (kMaxRings + 1): ring start offsets (scan-local)
   int* tmp_idx;                // 4 x n_total: per-ring lists before compaction
   int* ring_cnt;               // n_scans x kMaxRings x 4
-  unsigned long long* sortbuf; // 2 x n_total: sorted sector keys (sector at 2*(o+sp))
 };
 
 __device__ __forceinline__ bool point_valid(float4 p, double min_range) {
@@ -314,88 +311,24 @@ __global__ void __launch_bounds__(256) extract_curvature_kernel(ExtractView v, E
   v.gap[g] = gp;
 }
 
-// ---- wave-level bitonic sort of 64-bit keys (ascending) ----------------------------------------
-// keys[0..P) with P a power of two; every lane of the wave takes part.  DESC sorts descending; the loop
-// over k starts at k0 (k0 = P: only the final merge of an already bitonic sequence).
-template <bool DESC, class KeyPtr>
-__device__ __forceinline__ void wave_bitonic_sort(KeyPtr keys, int P, int lane, int k0 = 2) {
-  for (int k = k0; k <= P; k <<= 1) {
-    for (int j = k >> 1, lj = 31 - __clz(k >> 1); j > 0; j >>= 1, lj--) {
-      for (int t = lane; t < (P >> 1); t += 64) {
-        // t-th compare-exchange pair of this stage; j is a power of two: shifts, no division
-        const int lo = ((t >> lj) << (lj + 1)) + (t & (j - 1));
-        const int hi = lo + j;
-        const bool up = ((lo & k) == 0) != DESC;
-        const unsigned long long a = keys[lo], c = keys[hi];
-        if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-  }
+// ---- wave-wide extremum of a 64-bit key on the DPP network (no LDS crossbar): six exchange steps, every lane active ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long k) {
+  const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)k, (int)(unsigned)k, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(k >> 32), (int)(unsigned)(k >> 32), CTRL, ROW_MASK, 0xf, false);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
-
-// One wavefront per (scan, ring, sector): sort the sector's (curvature, index) keys ascending and
-// leave them at sortbuf[2*(o+sp) ...] (cnt entries).  Splitting the sort from the (serial) pick gives
-// six times more wavefronts for the part that dominates the instruction count.
-__global__ void __launch_bounds__(64 * kExWaves) extract_sort_kernel(ExtractView v, ExtractParams prm) {
-  __shared__ unsigned long long s_keys[kExWaves][kSortLds];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // grid = (scans, unit groups): scans on the FAST block index.  Only the first few unit groups of a
-  // scan have work (16 of 128 rings on a VLP-16); with groups on the fast index the busy workgroups
-  // shared a residue mod 32 and the round-robin dispatcher packed them onto 32 of the 256 CUs.
-  const int b = blockIdx.x;
-  const int unit = blockIdx.y * kExWaves + wave;                 // ring * sectors + sector
-  const int r = unit / prm.sectors, j = unit - r * prm.sectors;
-  if (r >= kMaxRings || v.status[b] != 0) return;
-  const int* tab = v.ring_tab + b * (kMaxRings + 1);
-  const int s = tab[r], len = tab[r + 1] - tab[r];
-  const int start = s + 5, end = s + len - 6;
-  if (len <= 0 || end - start < 6 || len > kRingCapacity) return;
-  const int sp = start + (end - start) * j / prm.sectors;
-  const int ep = start + (end - start) * (j + 1) / prm.sectors - 1;
-  const int cnt = ep - sp + 1;
-  if (cnt <= 0) return;
-  const int o = v.off[b];
-  const float* curv = v.curvature + o;
-  unsigned long long* dst = v.sortbuf + 2 * (size_t)(o + sp);   // 2*cnt >= P entries: disjoint per sector
-  int P = 1;
-  while (P < cnt) P <<= 1;
-  // keys: (curvature bits << 32) | index.  curvature >= 0, so the f32 bit pattern is monotone and
-  // the u64 order is exactly (curvature, index) ascending.
-  if (P <= kSortLds) {
-    unsigned long long* keys = s_keys[wave];
-    const int Q = P >> 1, R = P >> 3;
-    // A VLP-16 sector holds 298 keys: padding them to a 512-key network wastes 40 % of it.  When the keys beyond
-    // the first half fit an eighth (cnt <= 320 of 512), sort the first half ascending and that eighth descending
-    // at the END of the array, +inf in between: ascending then non-increasing is bitonic, one merge finishes
-    // (36 + 21/2 + 9*... = ~30 % fewer compare-exchange steps than the full network).
-    const bool split = P >= 128 && cnt <= Q + R;
-    for (int k = lane; k < P; k += 64) {
-      int src = k;
-      if (split && k >= Q) src = (k >= P - R) ? Q + (k - (P - R)) : cnt;       // middle: filler
-      keys[k] = (src < cnt) ? (((unsigned long long)__float_as_uint(curv[sp + src]) << 32) | (unsigned int)(sp + src)) : ~0ull;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (split) {
-      wave_bitonic_sort<false>(keys, Q, lane);
-      wave_bitonic_sort<true>(keys + (P - R), R, lane);
-      wave_bitonic_sort<false>(keys, P, lane, P);                          // the final merge only
-    } else {
-      wave_bitonic_sort<false>(keys, P, lane);
-    }
-    for (int k = lane; k < cnt; k += 64) dst[k] = keys[k];
-  } else {
-    for (int k = lane; k < P; k += 64)
-      dst[k] = (k < cnt) ? (((unsigned long long)__float_as_uint(curv[sp + k]) << 32) | (unsigned int)(sp + k)) : ~0ull;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    wave_bitonic_sort<false>(dst, P, lane);
-  }
+template <bool MAX>
+__device__ __forceinline__ unsigned long long wave_extremum_u64(unsigned long long k) {
+  auto pick = [](unsigned long long a, unsigned long long c) { return MAX ? (a > c ? a : c) : (a < c ? a : c); };
+  k = pick(k, dpp_u64<0xb1, 0xf>(k));      // quad_perm [1,0,3,2]
+  k = pick(k, dpp_u64<0x4e, 0xf>(k));      // quad_perm [2,3,0,1]
+  k = pick(k, dpp_u64<0x141, 0xf>(k));     // row_half_mirror
+  k = pick(k, dpp_u64<0x140, 0xf>(k));     // row_mirror
+  k = pick(k, dpp_u64<0x142, 0xa>(k));     // row_bcast:15 -> rows 1, 3
+  k = pick(k, dpp_u64<0x143, 0xc>(k));     // row_bcast:31 -> rows 2, 3
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 struct RingBits {
@@ -428,13 +361,25 @@ __device__ __forceinline__ void neighbour_span(const RingBits& gap, int q, int& 
   back = __clz((int)((b5 << 27) | (1u << 26)));      // leading zeros of the 5-bit field (0..5)
 }
 
+// One wavefront per (scan, ring).  The reference sorts every sector by curvature (std::sort, :263-267) and walks the
+// sorted order: descending for the <= 20 corner picks, ascending for the <= 4 flat picks, skipping points that an
+// earlier pick has suppressed.  Walking a sorted order and skipping the suppressed ones IS "take the largest (smallest)
+// not yet suppressed key", so no sort is needed: every lane holds its share of the sector's (curvature, index) keys in
+// registers (up to kPickCand per lane, 512 per sector: a VLP-16 sector has 298) with one `alive` bit each, a pick is one
+// wave-wide arg-max / arg-min on the DPP network, and the lanes whose candidates fall into the suppressed span clear
+// their bits.  Keys order like the sort's (curvature bits << 32 | index: curvature >= 0, so the u64 order is
+// (curvature, index) ascending).  Sectors with more than 512 points re-read curvature and the suppression mask per pick.
+// Round 1 had a bitonic sort kernel in front of this one (0.33 ms per 1 024 scans, LDS bound) plus the key round trip.
+constexpr int kPickCand = 8;
+
 __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView v, ExtractParams prm) {
-  __shared__ unsigned long long s_keys[kExWaves][kSortLds];
   __shared__ unsigned int s_picked[kExWaves][kRingCapacity / 32 + 2];
   __shared__ unsigned int s_corner[kExWaves][kRingCapacity / 32 + 2];
   __shared__ unsigned int s_gap[kExWaves][kRingCapacity / 32 + 2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x;                               // scans on the fast block index (see extract_sort_kernel)
+  const int b = blockIdx.x;                               // scans on the FAST block index: only the first few ring groups of a scan
+                                                          // have work (16 of 128 rings on a VLP-16); with groups on the fast index the busy
+                                                          // workgroups shared a residue mod 32 and landed on 32 of the 256 CUs
   const int r = blockIdx.y * kExWaves + wave;
   if (r >= kMaxRings) return;
   int* cnt_out = v.ring_cnt + ((size_t)b * kMaxRings + r) * 4;
@@ -454,11 +399,17 @@ __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView
   }
   uint8_t* label = v.label + o;
   const uint8_t* gapb = v.gap + o;
+  const float* curv = v.curvature + o;
   int* t_sharp = v.tmp_idx + 0 * (size_t)v.n_total + o + s;
   int* t_ls = v.tmp_idx + 1 * (size_t)v.n_total + o + s;
   int* t_flat = v.tmp_idx + 2 * (size_t)v.n_total + o + s;
   int* t_lf = v.tmp_idx + 3 * (size_t)v.n_total + o + s;
   RingBits picked{s_picked[wave]}, corner{s_corner[wave]}, gap{s_gap[wave]};
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   // ring-local bitmasks: bit k <-> scan-local index s + k
   for (int w0 = 0; w0 < len + 64; w0 += 64) {       // one extra round: the spare words behind the ring
     const int k = w0 + lane;
@@ -470,103 +421,102 @@ __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView
       corner.w[(w0 >> 5)] = 0; corner.w[(w0 >> 5) + 1] = 0;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  wave_sync();
   for (int j = 0; j < prm.sectors; j++) {
     const int sp = start + (end - start) * j / prm.sectors;                 // :256-259
     const int ep = start + (end - start) * (j + 1) / prm.sectors - 1;
     const int cnt = ep - sp + 1;
     if (cnt <= 0) continue;
-    // sorted (curvature, index) keys of this sector, produced by extract_sort_kernel
-    const unsigned long long* gkeys = v.sortbuf + 2 * (size_t)(o + sp);
-    const bool in_lds = (cnt <= kSortLds);
-    if (in_lds) {
-      unsigned long long* keys = s_keys[wave];
-      for (int k = lane; k < cnt; k += 64) keys[k] = gkeys[k];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    {
-      // The reference walks the sorted sector one candidate at a time; here the wave looks at 64 candidates at once
-      // (every lane tests its own candidate's `picked` bit), takes the first unpicked one in curvature order, marks
-      // its neighbourhood and looks again: one round per PICK (<= 20 + 4 per sector) instead of one per candidate.
-      const unsigned long long* keys = in_lds ? s_keys[wave] : gkeys;
-      // corner picks, descending curvature (:272-305)
-      int largest = 0;
-      bool done = false;
-      for (int base = 0; base < cnt && !done; base += 64) {
-        const int k = cnt - 1 - (base + lane);
-        const bool have = k >= 0;
-        const unsigned long long key = have ? keys[k] : 0ull;
-        const int ind = (int)(unsigned int)key;
-        const int q = ind - s;
-        const bool qual = have && ((double)__uint_as_float((unsigned int)(key >> 32)) > prm.curvature_threshold);
-        // sorted: the first non-qualifying candidate ends the pass (:275), so only the lanes before it count
-        const unsigned long long nq = __ballot(!qual);
-        const unsigned long long upto = nq ? ((1ull << (__ffsll((long long)nq) - 1)) - 1ull) : ~0ull;
-        if (nq) done = true;
-        for (;;) {
-          const bool unp = qual && !picked.get(q);
-          const unsigned long long m = __ballot(unp) & upto;
-          if (m == 0) break;
-          const int L = __ffsll((long long)m) - 1;
-          const int pind = __shfl(ind, L), pq = pind - s;
-          largest++;
-          if (largest > prm.max_less_sharp) { done = true; break; }            // :283-285 (no marking for this one)
-          int back, fwd;
-          neighbour_span(gap, pq, back, fwd);                  // runs of |p[i+1]-p[i]|^2 <= 0.05 around the pick
-          if (lane == 0) {
-            if (largest <= prm.max_sharp) { label[pind] = 1; t_sharp[n_sharp] = pind; t_ls[n_ls] = pind; }
-            else { label[pind] = 2; t_ls[n_ls] = pind; }
-            const unsigned int span = (2u << (back + fwd)) - 1u;   // back + fwd + 1 ones
-            picked.or_window(pq - back, span); corner.or_window(pq - back, span);
-          }
-          if (largest <= prm.max_sharp) n_sharp++;
-          n_ls++;
-          if (lane >= 1 && lane <= back) label[pind - lane] = 2;   // relabel the neighbours (:295, :302)
-          if (lane >= 1 && lane <= fwd) label[pind + lane] = 2;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-      }
-      // flat picks, ascending curvature (:307-336)
-      int smallest = 0;
-      done = false;
-      for (int base = 0; base < cnt && !done; base += 64) {
-        const int k = base + lane;
-        const bool have = k < cnt;
-        const unsigned long long key = have ? keys[k] : 0ull;
-        const int ind = (int)(unsigned int)key;
-        const int q = ind - s;
-        const bool qual = have && ((double)__uint_as_float((unsigned int)(key >> 32)) < prm.curvature_threshold);
-        const unsigned long long nq = __ballot(!qual);
-        const unsigned long long upto = nq ? ((1ull << (__ffsll((long long)nq) - 1)) - 1ull) : ~0ull;
-        if (nq) done = true;
-        for (;;) {
-          const bool unp = qual && !picked.get(q);
-          const unsigned long long m = __ballot(unp) & upto;
-          if (m == 0) break;
-          const int L = __ffsll((long long)m) - 1;
-          const int pind = __shfl(ind, L), pq = pind - s;
-          if (lane == 0) { label[pind] = 3; t_flat[n_flat] = pind; }
-          n_flat++;
-          smallest++;
-          if (smallest >= prm.max_flat) { done = true; break; }    // before neighbour marking, :317-319
-          int back, fwd;
-          neighbour_span(gap, pq, back, fwd);
-          if (lane == 0) picked.or_window(pq - back, (2u << (back + fwd)) - 1u);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool in_regs = cnt <= 64 * kPickCand;
+    // this lane's candidates: positions sp + lane + 64 t.  Bits of `alive`: not suppressed so far; `sharp_q` / `flat_q`:
+    // curvature above / below the threshold (compared as doubles, :275 / :312)
+    unsigned long long ck[kPickCand];
+    unsigned alive = 0, sharp_q = 0, flat_q = 0;
+    if (in_regs) {
+#pragma unroll
+      for (int t = 0; t < kPickCand; t++) {
+        const int pos = sp + lane + 64 * t;
+        ck[t] = 0;
+        if (pos <= ep) {
+          const float c = curv[pos];
+          ck[t] = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned int)pos;
+          if (!picked.get(pos - s)) alive |= 1u << t;
+          if ((double)c > prm.curvature_threshold) sharp_q |= 1u << t;
+          if ((double)c < prm.curvature_threshold) flat_q |= 1u << t;
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // best live candidate of this lane: the largest qualifying key (corner pass) or the smallest (flat pass); 0 / ~0 = none
+    auto lane_best = [&](bool corner_pass) __attribute__((always_inline)) {
+      unsigned long long best = corner_pass ? 0ull : ~0ull;
+      if (in_regs) {
+        const unsigned m = alive & (corner_pass ? sharp_q : flat_q);
+#pragma unroll
+        for (int t = 0; t < kPickCand; t++) {
+          const bool on = (m >> t) & 1u;
+          if (corner_pass) best = (on && ck[t] > best) ? ck[t] : best;
+          else best = (on && ck[t] < best) ? ck[t] : best;
+        }
+      } else {
+        for (int pos = sp + lane; pos <= ep; pos += 64) {
+          const float c = curv[pos];
+          const bool q = corner_pass ? ((double)c > prm.curvature_threshold) : ((double)c < prm.curvature_threshold);
+          if (!q || picked.get(pos - s)) continue;
+          const unsigned long long key = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned int)pos;
+          if (corner_pass) best = key > best ? key : best; else best = key < best ? key : best;
+        }
+      }
+      return best;
+    };
+    // scan-local positions [a, c] have just been suppressed: clear the alive bits of this lane's candidates in there
+    auto suppress = [&](int a, int c) __attribute__((always_inline)) {
+      if (!in_regs) return;
+#pragma unroll
+      for (int t = 0; t < kPickCand; t++) {
+        const int pos = sp + lane + 64 * t;
+        if (pos >= a && pos <= c) alive &= ~(1u << t);
+      }
+    };
+    // corner picks, descending curvature (:272-305)
+    int largest = 0;
+    for (;;) {
+      const unsigned long long kmax = wave_extremum_u64<true>(lane_best(true));
+      if (kmax == 0ull) break;                                           // nothing unsuppressed above the threshold is left
+      const int pind = (int)(unsigned int)kmax, pq = pind - s;
+      largest++;
+      if (largest > prm.max_less_sharp) break;                           // :283-285 (no marking for this one)
+      int back, fwd;
+      neighbour_span(gap, pq, back, fwd);                  // runs of |p[i+1]-p[i]|^2 <= 0.05 around the pick
+      if (lane == 0) {
+        if (largest <= prm.max_sharp) { label[pind] = 1; t_sharp[n_sharp] = pind; t_ls[n_ls] = pind; }
+        else { label[pind] = 2; t_ls[n_ls] = pind; }
+        const unsigned int span = (2u << (back + fwd)) - 1u;   // back + fwd + 1 ones
+        picked.or_window(pq - back, span); corner.or_window(pq - back, span);
+      }
+      if (largest <= prm.max_sharp) n_sharp++;
+      n_ls++;
+      if (lane >= 1 && lane <= back) label[pind - lane] = 2;   // relabel the neighbours (:295, :302)
+      if (lane >= 1 && lane <= fwd) label[pind + lane] = 2;
+      suppress(pind - back, pind + fwd);
+      wave_sync();
+    }
+    // flat picks, ascending curvature (:307-336)
+    int smallest = 0;
+    for (;;) {
+      const unsigned long long kmin = wave_extremum_u64<false>(lane_best(false));
+      if (kmin == ~0ull) break;
+      const int pind = (int)(unsigned int)kmin, pq = pind - s;
+      if (lane == 0) { label[pind] = 3; t_flat[n_flat] = pind; }
+      n_flat++;
+      smallest++;
+      if (smallest >= prm.max_flat) break;                     // before neighbour marking, :317-319
+      int back, fwd;
+      neighbour_span(gap, pq, back, fwd);
+      if (lane == 0) picked.or_window(pq - back, (2u << (back + fwd)) - 1u);
+      suppress(pind - back, pind + fwd);
+      wave_sync();
+    }
+    wave_sync();
     // less-flat = positions of this sector not labelled SHARP / LESS_SHARP so far (:338-344)
     for (int k0 = sp; k0 <= ep; k0 += 64) {
       const int k = k0 + lane;

@@ -1,0 +1,16 @@
+#!/bin/bash
+# kernel-trace summary of any command on the GPU box: bash tools/prof_cmd.sh <tag> <command...>
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- "$@" > $OUT/log.txt 2>&1
+F=$(find $OUT -name "*kernel_stats.csv" | head -1)
+python - "$F" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:24]:
+    print("%-90s calls %6s avg %10.1f us  total %6.2f %%" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+PY
+cp "$F" $OUT/kernel_stats.csv; find $OUT -type f ! -name kernel_stats.csv ! -name log.txt -delete
