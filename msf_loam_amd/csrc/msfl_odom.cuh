@@ -332,8 +332,13 @@ constexpr int kOdomLanes = MSFL_ODOM_LANES;             // lanes cooperating on 
 #define MSFL_ODOM_BLOCK 64
 #endif
 constexpr int kOdomBlock = MSFL_ODOM_BLOCK;             // threads per workgroup of the column-grid query kernel
-constexpr int kOdomMidLevel = 2;
-constexpr int kOdomMaxLevel = 6;                        // gap >= 6 m  >  sqrt(25): nothing outside can pass the 25 m^2 gate
+// Half-widths of the walked column squares: 3x3, 5x5, 7x7, 9x9, 13x13.  Every level re-walks the inner square, so a fine
+// progression only pays when few queries go far: measured 1.91 -> 1.84 ms per 1 024 pairs against the round-1 schedule
+// (1, 2, 6).  Columns of 0.5 m with (1, 2, 3, 5, 8, 12) visit 24 % fewer candidates and run 35 % SLOWER (2.37 ms): the
+// kernel is bound by the dependent run-bound -> run loads of each row, not by the candidates (rejected).
+constexpr int kOdomLevels = 5;
+__device__ __forceinline__ int odom_level_radius(int l) { return l < 4 ? l + 1 : 6; }
+constexpr int kOdomMaxLevel = 6;
 
 struct OdomPairDesc { int ox, oy, W, H; };              // column (cx, cy) = (floor(x) - ox, floor(y) - oy), 0 <= cx < W
 
@@ -429,34 +434,37 @@ odom_bin_kernel(const float4* __restrict__ pts_all, const uint16_t* __restrict__
 // L lanes (a power of two, one query per L-lane group) walk the (2r+1)^2 column square around
 // column (cx, cy): every row's run is read L targets at a time (coalesced); f(float4) per target.
 template <int L, class F>
-__device__ __forceinline__ void odom_walk(const OdomIndex& ix, const unsigned* __restrict__ tab, const float4* __restrict__ sorted,
+__device__ __forceinline__ void odom_walk_runs3(const float4* __restrict__ sorted, const int (&b0)[3], const int (&b1)[3], int sl, F&& f) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int i = b0[k] + sl;
+    for (; i + 3 * L < b1[k]; i += 4 * L) {                 // four loads in flight per lane
+      const float4 p0 = sorted[i], p1 = sorted[i + L], p2 = sorted[i + 2 * L], p3 = sorted[i + 3 * L];
+      f(p0); f(p1); f(p2); f(p3);
+    }
+    for (; i < b1[k]; i += L) f(sorted[i]);
+  }
+}
+
+// run bounds of the (up to) three rows of the 3 x 3 column square: row-major table, the run of columns [x0, x1] of a
+// row ends where column x1 + 1 starts; all six loads are requested together and are uniform inside the lane group
+__device__ __forceinline__ void odom_runs3(const unsigned* __restrict__ tab, int W, int H, int cx, int cy, int (&b0)[3], int (&b1)[3]) {
+  const int x0 = max(cx - 1, 0), x1 = min(cx + 1, W - 1);
+  const int y0 = max(cy - 1, 0), y1 = min(cy + 1, H - 1);
+  const bool none = x0 > x1 || y0 > y1;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    b0[k] = 0; b1[k] = 0;
+    if (!none && y0 + k <= y1) { b0[k] = (int)tab[(y0 + k) * W + x0]; b1[k] = (int)tab[(y0 + k) * W + x1 + 1]; }
+  }
+}
+
+template <int L, class F>
+__device__ __forceinline__ void odom_walk(const unsigned* __restrict__ tab, const float4* __restrict__ sorted,
                                           int W, int H, int cx, int cy, int r, int sl, F&& f) {
   const int x0 = max(cx - r, 0), x1 = min(cx + r, W - 1);
   const int y0 = max(cy - r, 0), y1 = min(cy + r, H - 1);
   if (x0 > x1 || y0 > y1) return;
-  // row-major table: the run of columns [x0, x1] of a row ends where column x1 + 1 starts; the two loads are
-  // uniform inside the lane group (one transaction)
-  if (y1 - y0 <= 2) {
-    // the common 3x3 walk: all six run bounds are requested before the first run is read, so their latency
-    // is paid once instead of once per row
-    int b0[3], b1[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int y = min(y0 + k, y1);
-      b0[k] = (int)tab[y * W + x0]; b1[k] = (int)tab[y * W + x1 + 1];
-      if (y0 + k > y1) b1[k] = b0[k];                       // fewer than three rows: an empty run
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      int i = b0[k] + sl;
-      for (; i + 3 * L < b1[k]; i += 4 * L) {                 // four loads in flight per lane
-        const float4 p0 = sorted[i], p1 = sorted[i + L], p2 = sorted[i + 2 * L], p3 = sorted[i + 3 * L];
-        f(p0); f(p1); f(p2); f(p3);
-      }
-      for (; i < b1[k]; i += L) f(sorted[i]);
-    }
-    return;
-  }
   for (int y = y0; y <= y1; y++) {
     const int b0 = (int)tab[y * W + x0], b1 = (int)tab[y * W + x1 + 1];
     for (int i = b0 + sl; i < b1; i += L) f(sorted[i]);
@@ -525,61 +533,78 @@ assoc_scan2scan_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const doubl
   const float4* sorted = ix.sorted + s0;
   // Running minima are packed keys (f32 distance bits << 32 | tie word): distances are >= 0, so one
   // unsigned compare realises (distance, tie) lexicographic order.
+  int b0[3], b1[3];
+  odom_runs3(tab, pd.W, pd.H, cx, cy, b0, b1);                     // the 3 x 3 square serves both walks
   // ---- exact 1-NN (:169), ties -> lower index.  Tie word = ring << 24 | index: on a ring-monotone cloud
   //      ordering by (ring, index) is ordering by index ----
   unsigned long long kbest = ~0ull;
-  for (int l = 0; l < 3; l++) {
-    const int r = l == 0 ? 1 : l == 1 ? kOdomMidLevel : kOdomMaxLevel;
-    odom_walk<L>(ix, tab, sorted, pd.W, pd.H, cx, cy, r, sl, [&](const float4 p) __attribute__((always_inline)) {
-      const unsigned long long k = ((unsigned long long)__float_as_uint(odom_dist(p, q)) << 32) | (unsigned)__float_as_int(p.w);
-      kbest = k < kbest ? k : kbest;
-    });
+  auto nearest = [&](const float4 p) __attribute__((always_inline)) {
+    const unsigned long long k = ((unsigned long long)__float_as_uint(odom_dist(p, q)) << 32) | (unsigned)__float_as_int(p.w);
+    kbest = k < kbest ? k : kbest;
+  };
+  int l1 = 0;                                                      // the level the 1-NN walk ended on
+  for (int l = 0; l < kOdomLevels; l++) {
+    const int r = odom_level_radius(l);
+    l1 = l;
+    if (l == 0) odom_walk_runs3<L>(sorted, b0, b1, sl, nearest);
+    else odom_walk<L>(tab, sorted, pd.W, pd.H, cx, cy, r, sl, nearest);
     kbest = group_min_key<L>(kbest);
     if (__uint_as_float((unsigned)(kbest >> 32)) < odom_gap_sq(q, fx, fy, r)) break;
   }
   if (!(__uint_as_float((unsigned)(kbest >> 32)) < thr)) { if (sl < kOut) out[sl] = 0.0; return; }    // :87 / :173 (NaN / none: not <)
   const int closest = (int)((unsigned)kbest & 0xffffffu), id = (int)((unsigned)kbest >> 24 & 0xffu);
-  // ---- ring-window minima (:183-232): forward ties -> lowest index, backward ties -> highest index
-  //      (tie word 0xffffff - index); tie word 0xffffffff = nothing found ----
-  const float hi_ring = (float)id + (float)ov.nearby_scan, lo_ring = (float)id - (float)ov.nearby_scan;
-  const unsigned long long none = ((unsigned long long)__float_as_uint(thr) << 32) | 0xffffffffull;
-  unsigned long long kf2, kf3, kb2, kb3;
-  for (int l = 0; l < 3; l++) {
-    const int r = l == 0 ? 1 : l == 1 ? kOdomMidLevel : kOdomMaxLevel;
-    kf2 = kf3 = kb2 = kb3 = none;                                   // each level re-walks the inner square too
-    odom_walk<L>(ix, tab, sorted, pd.W, pd.H, cx, cy, r, sl, [&](const float4 p) __attribute__((always_inline)) {
-      const int w = __float_as_int(p.w), j = w & 0xffffff, rj = (int)((unsigned)w >> 24);
-      if (j == closest || (float)rj > hi_ring || (float)rj < lo_ring) return;
-      const float d = odom_dist(p, q);
-      if (!(d < thr)) return;                                    // every running minimum starts at the 25 m^2 gate
-      // branch-free updates (selects): branches here make the compiler address the minima through memory
-      const bool fwd = j > closest, same = fwd ? rj <= id : rj >= id;
-      if (EDGE && same) return;                                  // edges take their second point from other rings only (:96, :121)
-      const unsigned long long kd = (unsigned long long)__float_as_uint(d) << 32;
-      const unsigned long long kf = kd | (unsigned)j, kb = kd | (unsigned)(0xffffff - j);
-      if (EDGE) {                                                // the second point of an edge plays the role of min2
-        kf2 = (fwd && kf < kf2) ? kf : kf2;
-        kb2 = (!fwd && kb < kb2) ? kb : kb2;
-      } else {
-        kf2 = (fwd && same && kf < kf2) ? kf : kf2;
-        kf3 = (fwd && !same && kf < kf3) ? kf : kf3;
-        kb2 = (!fwd && same && kb < kb2) ? kb : kb2;
-        kb3 = (!fwd && !same && kb < kb3) ? kb : kb3;
-      }
-    });
-    kf2 = group_min_key<L>(kf2); kb2 = group_min_key<L>(kb2);
-    if (!EDGE) { kf3 = group_min_key<L>(kf3); kb3 = group_min_key<L>(kb3); }
+  // ---- ring-window minima (:183-232).  The reference sweeps forward from `closest` (rings up to id + nearby_scan), then
+  //      backward (down to id - nearby_scan), with running minima that start at the gate and are replaced on strict '<':
+  //      at equal distance a forward candidate beats a backward one, the forward ones tie to the lowest index and the
+  //      backward ones to the highest.  That is ONE lexicographic minimum per output with the tie word
+  //          j > closest:  j - closest            (1 .. 2^24 - 1)
+  //          j < closest:  2^24 + (closest - j)
+  //      On a ring-monotone cloud "ring <= id forward / ring >= id backward" (min2) is "ring == id", and the rest of the
+  //      window is min3.  `none` = gate distance with tie 0: a key is below it exactly when its distance is below the gate.
+  //      The window test is done on integers ----
+  const float hi_ring = (float)id + (float)ov.nearby_scan, lo_ring = (float)id - (float)ov.nearby_scan;   // as the brute-force kernel forms them
+  // (float)rj > hi_ring  <=>  rj > floor(hi_ring);  (float)rj < lo_ring  <=>  rj < ceil(lo_ring)  (rj an integer; a NaN bound excludes nothing)
+  const int hi_i = hi_ring == hi_ring ? (int)fminf(fmaxf(floorf(hi_ring), -1048576.f), 1048576.f) : 1048576;
+  const int lo_i = lo_ring == lo_ring ? (int)fminf(fmaxf(ceilf(lo_ring), -1048576.f), 1048576.f) : -1048576;
+  const bool window = hi_i >= lo_i;
+  const unsigned span = window ? (unsigned)(hi_i - lo_i) : 0u;
+  const int lo_w = window ? lo_i : (1 << 22);                      // empty window: every ring is "outside"
+  const unsigned long long none = (unsigned long long)__float_as_uint(thr) << 32;
+  unsigned long long k2, k3;
+  auto windowed = [&](const float4 p) __attribute__((always_inline)) {
+    const int w = __float_as_int(p.w), j = w & 0xffffff, rj = (int)((unsigned)w >> 24);
+    const int t = j - closest;
+    const bool same = rj == id;
+    const bool skip = (unsigned)(rj - lo_w) > span || t == 0 || (EDGE && same);   // edges take their second point from other rings only (:96, :121)
+    const float d = odom_dist(p, q);
+    const unsigned tie = t > 0 ? (unsigned)t : 0x1000000u - (unsigned)t;
+    unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | tie;
+    key = skip ? ~0ull : key;                                    // (a NaN distance has bits above the gate's: never below `none`)
+    // branch-free updates (selects): branches here make the compiler address the minima through memory
+    if (EDGE) k2 = key < k2 ? key : k2;                            // the second point of an edge plays the role of min2
+    else {
+      k2 = (same && key < k2) ? key : k2;
+      k3 = (!same && key < k3) ? key : k3;
+    }
+  };
+  // the windowed minima are no closer than the 1-NN: the levels that could not bound IT cannot bound them either
+  for (int l = l1; l < kOdomLevels; l++) {
+    const int r = odom_level_radius(l);
+    k2 = k3 = none;                                                // each level re-walks the inner square too
+    if (l == 0) odom_walk_runs3<L>(sorted, b0, b1, sl, windowed);
+    else odom_walk<L>(tab, sorted, pd.W, pd.H, cx, cy, r, sl, windowed);
+    k2 = group_min_key<L>(k2);
+    if (!EDGE) k3 = group_min_key<L>(k3);
     const float g = odom_gap_sq(q, fx, fy, r);
-    const float m2 = __uint_as_float((unsigned)((kf2 < kb2 ? kf2 : kb2) >> 32)), m3 = __uint_as_float((unsigned)((kf3 < kb3 ? kf3 : kb3) >> 32));
-    if (m2 < g && (EDGE || m3 < g)) break;
+    if (__uint_as_float((unsigned)(k2 >> 32)) < g && (EDGE || __uint_as_float((unsigned)(k3 >> 32)) < g)) break;
   }
   if (sl != 0) return;
-  const float f2 = __uint_as_float((unsigned)(kf2 >> 32)), f3 = __uint_as_float((unsigned)(kf3 >> 32));
-  const float b2 = __uint_as_float((unsigned)(kb2 >> 32)), b3 = __uint_as_float((unsigned)(kb3 >> 32));
-  const int jf2 = (unsigned)kf2 == 0xffffffffu ? -1 : (int)(unsigned)kf2, jf3 = (unsigned)kf3 == 0xffffffffu ? -1 : (int)(unsigned)kf3;
-  const int jb2 = (unsigned)kb2 == 0xffffffffu ? -1 : 0xffffff - (int)(unsigned)kb2, jb3 = (unsigned)kb3 == 0xffffffffu ? -1 : 0xffffff - (int)(unsigned)kb3;
-  const int min2 = (jb2 >= 0 && b2 < f2) ? jb2 : jf2;           // backward continues the forward minimum with strict '<'
-  const int min3 = (jb3 >= 0 && b3 < f3) ? jb3 : jf3;
+  auto index_of = [&](unsigned long long k) {
+    if (k == none) return -1;
+    const unsigned tie = (unsigned)k;
+    return tie < 0x1000000u ? closest + (int)tie : closest - (int)(tie - 0x1000000u);
+  };
+  const int min2 = index_of(k2), min3 = EDGE ? -1 : index_of(k3);
   d3 C = mk3(0, 0, 0), N = mk3(0, 0, 0);
   if (EDGE) {
     if (min2 >= 0) {                                             // :143-162
