@@ -14,13 +14,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "msfl_math.cuh"
 
 namespace msfl {
 
 constexpr int kMaxRings = 128;          // kMaxScanNum, msf_loam_node.cc:79
-constexpr int kRingCapacity = 8192;     // points per ring handled by the LDS bitmasks
+constexpr int kRingCapacity = 8128;     // points per ring handled by the LDS bitmasks (256 words each with the two spare ones: the pick kernel's
+                                        // workgroup takes exactly 20 KB and eight of them share a CU)
 
 struct ExtractParams {
   double min_range;
@@ -279,20 +281,32 @@ __device__ __forceinline__ int find_scan_off_wave(const int* __restrict__ off, i
   return b;
 }
 
+// 256 consecutive points of the concatenated batch per workgroup, staged once into an LDS tile with a five-point halo on
+// either side: every point is fetched from global memory once instead of twelve times (its own load, the eleven-point
+// window of its neighbours and the gap test), which had the kernel waiting on the vector L1 (111 M cache accesses per
+// 1 024 scans for 24 M points).  Halo slots outside the batch stay unread: the margin test keeps the window inside the scan.
 __global__ void __launch_bounds__(256) extract_curvature_kernel(ExtractView v, ExtractParams prm) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float4 s_p[256 + 10];
+  const int g0 = blockIdx.x * 256, tid = threadIdx.x;
+  const int g = g0 + tid;
+  if (g < v.n_total) s_p[tid + 5] = v.full_pts[g];
+  if (tid < 10) {
+    const int h = tid < 5 ? g0 - 5 + tid : g0 + 256 + (tid - 5);
+    if (h >= 0 && h < v.n_total) s_p[tid < 5 ? tid : 256 + tid] = v.full_pts[h];
+  }
+  __syncthreads();
   if (g >= v.n_total) return;
   const int b = find_scan_off_wave(v.off, v.n_scans, g);
   const int o = v.off[b];
   const int i = g - o;
   const int N = v.n_full[b];
   if (i >= N) return;
-  const float4* c = v.full_pts + o;
+  const float4* c = s_p + tid + 5;                          // c[k] = point i + k of this scan, |k| <= 5
   float curv = 0.f;
   if (i >= 5 && i < N - 5) {
     // f32 sums in source order (:214-234), f64 squares, f32 store (:236)
-    const float4 m5 = c[i - 5], m4 = c[i - 4], m3 = c[i - 3], m2 = c[i - 2], m1 = c[i - 1], p0 = c[i];
-    const float4 p1 = c[i + 1], p2 = c[i + 2], p3 = c[i + 3], p4 = c[i + 4], p5 = c[i + 5];
+    const float4 m5 = c[-5], m4 = c[-4], m3 = c[-3], m2 = c[-2], m1 = c[-1], p0 = c[0];
+    const float4 p1 = c[1], p2 = c[2], p3 = c[3], p4 = c[4], p5 = c[5];
     const float dx = m5.x + m4.x + m3.x + m2.x + m1.x - 10 * p0.x + p1.x + p2.x + p3.x + p4.x + p5.x;
     const float dy = m5.y + m4.y + m3.y + m2.y + m1.y - 10 * p0.y + p1.y + p2.y + p3.y + p4.y + p5.y;
     const float dz = m5.z + m4.z + m3.z + m2.z + m1.z - 10 * p0.z + p1.z + p2.z + p3.z + p4.z + p5.z;
@@ -303,7 +317,7 @@ __global__ void __launch_bounds__(256) extract_curvature_kernel(ExtractView v, E
   v.label[g] = 0;
   uint8_t gp = 1;
   if (i + 1 < N) {
-    const float4 a = c[i + 1], q = c[i];
+    const float4 a = c[1], q = c[0];
     const float ex = a.x - q.x, ey = a.y - q.y, ez = a.z - q.z;
     const float s = ex * ex + ey * ey + ez * ez;           // Vector3f squaredNorm
     gp = ((double)s > prm.neighbor_gap_sq) ? 1 : 0;        // :293,300,326,332
@@ -361,21 +375,43 @@ __device__ __forceinline__ void neighbour_span(const RingBits& gap, int q, int& 
   back = __clz((int)((b5 << 27) | (1u << 26)));      // leading zeros of the 5-bit field (0..5)
 }
 
+// wave-wide extremum of a 32-bit word, same six DPP steps as wave_extremum_u64
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned k) { return (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, CTRL, ROW_MASK, 0xf, false); }
+template <bool MAX>
+__device__ __forceinline__ unsigned wave_extremum_u32(unsigned k) {
+  auto pick = [](unsigned a, unsigned c) { return MAX ? (a > c ? a : c) : (a < c ? a : c); };
+  k = pick(k, dpp_u32<0xb1, 0xf>(k));
+  k = pick(k, dpp_u32<0x4e, 0xf>(k));
+  k = pick(k, dpp_u32<0x141, 0xf>(k));
+  k = pick(k, dpp_u32<0x140, 0xf>(k));
+  k = pick(k, dpp_u32<0x142, 0xa>(k));
+  k = pick(k, dpp_u32<0x143, 0xc>(k));
+  return (unsigned)__builtin_amdgcn_readlane((int)k, 63);
+}
+
 // One wavefront per (scan, ring).  The reference sorts every sector by curvature (std::sort, :263-267) and walks the
 // sorted order: descending for the <= 20 corner picks, ascending for the <= 4 flat picks, skipping points that an
 // earlier pick has suppressed.  Walking a sorted order and skipping the suppressed ones IS "take the largest (smallest)
-// not yet suppressed key", so no sort is needed: every lane holds its share of the sector's (curvature, index) keys in
-// registers (up to kPickCand per lane, 512 per sector: a VLP-16 sector has 298) with one `alive` bit each, a pick is one
-// wave-wide arg-max / arg-min on the DPP network, and the lanes whose candidates fall into the suppressed span clear
-// their bits.  Keys order like the sort's (curvature bits << 32 | index: curvature >= 0, so the u64 order is
-// (curvature, index) ascending).  Sectors with more than 512 points re-read curvature and the suppression mask per pick.
+// not yet suppressed key", so no sort is needed.  The sector's curvatures sit in an LDS array of f32 bit patterns
+// (curvature >= 0: the u32 order is the f32 order), written once per pass from the lanes' registers: for the corner pass
+// a word is 0 when the point is not above the threshold or suppressed, for the flat pass ~0 when it is not below it or
+// suppressed (one array, not two: LDS is what limits the wavefronts per SIMD here, and the kernel is a latency chain).
+// A pick is: every
+// lane takes the extremum of its <= 8 words (position sp + lane + 64 t, so ties inside a lane resolve by t), one
+// wave-wide DPP extremum, a ballot for the lane that holds it (several lanes with the same curvature bits: a second
+// reduction over their positions), and the <= 11 suppressed positions are overwritten by their lanes.  Ties order like
+// the sort's keys (curvature bits << 32 | index): the corner pass takes the highest index, the flat pass the lowest.
+// Sectors with more than 512 points (a VLP-16 sector has 298) re-read curvature and the suppression mask per pick.
 // Round 1 had a bitonic sort kernel in front of this one (0.33 ms per 1 024 scans, LDS bound) plus the key round trip.
 constexpr int kPickCand = 8;
+constexpr int kPickSector = 64 * kPickCand;
 
 __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView v, ExtractParams prm) {
   __shared__ unsigned int s_picked[kExWaves][kRingCapacity / 32 + 2];
   __shared__ unsigned int s_corner[kExWaves][kRingCapacity / 32 + 2];
   __shared__ unsigned int s_gap[kExWaves][kRingCapacity / 32 + 2];
+  __shared__ unsigned int s_cand[kExWaves][kPickSector];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x;                               // scans on the FAST block index: only the first few ring groups of a scan
                                                           // have work (16 of 128 rings on a VLP-16); with groups on the fast index the busy
@@ -384,11 +420,13 @@ __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView
   if (r >= kMaxRings) return;
   int* cnt_out = v.ring_cnt + ((size_t)b * kMaxRings + r) * 4;
   const int* tab = v.ring_tab + b * (kMaxRings + 1);
-  const int s = tab[r], len = tab[r + 1] - tab[r];
-  const int o = v.off[b];
+  // the ring's bounds are the same in every lane: say so (readfirstlane), and the sector bounds, the pick loops' trip
+  // counts and the picked positions all live in scalar registers with scalar branches around them
+  const int s = __builtin_amdgcn_readfirstlane(tab[r]), len = __builtin_amdgcn_readfirstlane(tab[r + 1]) - s;
+  const int o = __builtin_amdgcn_readfirstlane(v.off[b]);
   int n_sharp = 0, n_ls = 0, n_flat = 0, n_lf = 0;
   const int start = s + 5, end = s + len - 6;                               // :192-194
-  const bool active = (v.status[b] == 0) && len > 0 && (end - start >= 6);  // :252
+  const bool active = (__builtin_amdgcn_readfirstlane(v.status[b]) == 0) && len > 0 && (end - start >= 6);  // :252
   if (!active) {
     if (lane == 0) { cnt_out[0] = 0; cnt_out[1] = 0; cnt_out[2] = 0; cnt_out[3] = 0; }
     return;
@@ -405,6 +443,7 @@ __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView
   int* t_flat = v.tmp_idx + 2 * (size_t)v.n_total + o + s;
   int* t_lf = v.tmp_idx + 3 * (size_t)v.n_total + o + s;
   RingBits picked{s_picked[wave]}, corner{s_corner[wave]}, gap{s_gap[wave]};
+  unsigned int* cand = s_cand[wave];
   auto wave_sync = [] {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -427,62 +466,68 @@ __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView
     const int ep = start + (end - start) * (j + 1) / prm.sectors - 1;
     const int cnt = ep - sp + 1;
     if (cnt <= 0) continue;
-    const bool in_regs = cnt <= 64 * kPickCand;
-    // this lane's candidates: positions sp + lane + 64 t.  Bits of `alive`: not suppressed so far; `sharp_q` / `flat_q`:
-    // curvature above / below the threshold (compared as doubles, :275 / :312)
-    unsigned long long ck[kPickCand];
-    unsigned alive = 0, sharp_q = 0, flat_q = 0;
-    if (in_regs) {
+    const bool in_lds = cnt <= kPickSector;
+    // thresholds compared as doubles (:275 / :312); points an earlier pick has suppressed are dead.  All eight loads are
+    // issued before the first is used (clamped index, no branch around them)
+    float cv[kPickCand];
+    auto stage = [&](auto corner_pass_t) __attribute__((always_inline)) {
+      constexpr bool kCorner = decltype(corner_pass_t)::value;
 #pragma unroll
       for (int t = 0; t < kPickCand; t++) {
-        const int pos = sp + lane + 64 * t;
-        ck[t] = 0;
-        if (pos <= ep) {
-          const float c = curv[pos];
-          ck[t] = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned int)pos;
-          if (!picked.get(pos - s)) alive |= 1u << t;
-          if ((double)c > prm.curvature_threshold) sharp_q |= 1u << t;
-          if ((double)c < prm.curvature_threshold) flat_q |= 1u << t;
-        }
+        const int k = lane + 64 * t, pos = sp + k;
+        const bool live = pos <= ep && !picked.get(min(pos, ep) - s);
+        const float c = cv[t];
+        if (kCorner) cand[k] = (live && (double)c > prm.curvature_threshold) ? __float_as_uint(c) : 0u;
+        else cand[k] = (live && (double)c < prm.curvature_threshold) ? __float_as_uint(c) : ~0u;
       }
+      wave_sync();
+    };
+    if (in_lds) {
+#pragma unroll
+      for (int t = 0; t < kPickCand; t++) cv[t] = curv[min(sp + lane + 64 * t, ep)];
+      stage(std::true_type{});
     }
-    // best live candidate of this lane: the largest qualifying key (corner pass) or the smallest (flat pass); 0 / ~0 = none
-    auto lane_best = [&](bool corner_pass) __attribute__((always_inline)) {
-      unsigned long long best = corner_pass ? 0ull : ~0ull;
-      if (in_regs) {
-        const unsigned m = alive & (corner_pass ? sharp_q : flat_q);
+    // The arg-max (corner pass) / arg-min (flat pass) of the live candidates as a scan-local position, -1 = none left.
+    auto select = [&](auto corner_pass_t) __attribute__((always_inline)) -> int {
+      constexpr bool kCorner = decltype(corner_pass_t)::value;
+      if (in_lds) {
+        const unsigned int* c = cand;
+        unsigned int best = kCorner ? 0u : ~0u, tb = 0;
 #pragma unroll
         for (int t = 0; t < kPickCand; t++) {
-          const bool on = (m >> t) & 1u;
-          if (corner_pass) best = (on && ck[t] > best) ? ck[t] : best;
-          else best = (on && ck[t] < best) ? ck[t] : best;
+          const unsigned int x = c[lane + 64 * t];
+          const bool take = kCorner ? x >= best : x < best;          // ties inside a lane: highest t (corner) / lowest t (flat)
+          best = take ? x : best; tb = take ? (unsigned)t : tb;
         }
-      } else {
-        for (int pos = sp + lane; pos <= ep; pos += 64) {
-          const float c = curv[pos];
-          const bool q = corner_pass ? ((double)c > prm.curvature_threshold) : ((double)c < prm.curvature_threshold);
-          if (!q || picked.get(pos - s)) continue;
-          const unsigned long long key = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned int)pos;
-          if (corner_pass) best = key > best ? key : best; else best = key < best ? key : best;
-        }
+        const unsigned int ext = wave_extremum_u32<kCorner>(best);
+        if (ext == (kCorner ? 0u : ~0u)) return -1;
+        const unsigned long long holders = __ballot(best == ext);
+        const unsigned int k = (unsigned)lane + 64u * tb;
+        if (__popcll(holders) == 1) return sp + __builtin_amdgcn_readlane((int)k, __ffsll((long long)holders) - 1);
+        return sp + (int)wave_extremum_u32<kCorner>(best == ext ? k : (kCorner ? 0u : ~0u));
       }
-      return best;
+      unsigned long long best = kCorner ? 0ull : ~0ull;
+      for (int pos = sp + lane; pos <= ep; pos += 64) {
+        const float c = curv[pos];
+        const bool q = kCorner ? ((double)c > prm.curvature_threshold) : ((double)c < prm.curvature_threshold);
+        if (!q || picked.get(pos - s)) continue;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned int)pos;
+        if (kCorner) best = key > best ? key : best; else best = key < best ? key : best;
+      }
+      best = wave_extremum_u64<kCorner>(best);
+      return best == (kCorner ? 0ull : ~0ull) ? -1 : (int)(unsigned int)best;
     };
-    // scan-local positions [a, c] have just been suppressed: clear the alive bits of this lane's candidates in there
-    auto suppress = [&](int a, int c) __attribute__((always_inline)) {
-      if (!in_regs) return;
-#pragma unroll
-      for (int t = 0; t < kPickCand; t++) {
-        const int pos = sp + lane + 64 * t;
-        if (pos >= a && pos <= c) alive &= ~(1u << t);
-      }
+    // scan-local positions [a, a + n) have just been suppressed (n <= 11)
+    auto suppress = [&](int a, int n, unsigned int dead) __attribute__((always_inline)) {
+      const int pos = a + lane;
+      if (in_lds && lane < n && pos >= sp && pos <= ep) cand[pos - sp] = dead;
     };
     // corner picks, descending curvature (:272-305)
     int largest = 0;
     for (;;) {
-      const unsigned long long kmax = wave_extremum_u64<true>(lane_best(true));
-      if (kmax == 0ull) break;                                           // nothing unsuppressed above the threshold is left
-      const int pind = (int)(unsigned int)kmax, pq = pind - s;
+      const int pind = select(std::true_type{});
+      if (pind < 0) break;                                               // nothing unsuppressed above the threshold is left
+      const int pq = pind - s;
       largest++;
       if (largest > prm.max_less_sharp) break;                           // :283-285 (no marking for this one)
       int back, fwd;
@@ -497,15 +542,16 @@ __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView
       n_ls++;
       if (lane >= 1 && lane <= back) label[pind - lane] = 2;   // relabel the neighbours (:295, :302)
       if (lane >= 1 && lane <= fwd) label[pind + lane] = 2;
-      suppress(pind - back, pind + fwd);
+      suppress(pind - back, back + fwd + 1, 0u);
       wave_sync();
     }
     // flat picks, ascending curvature (:307-336)
+    if (in_lds) stage(std::false_type{});
     int smallest = 0;
     for (;;) {
-      const unsigned long long kmin = wave_extremum_u64<false>(lane_best(false));
-      if (kmin == ~0ull) break;
-      const int pind = (int)(unsigned int)kmin, pq = pind - s;
+      const int pind = select(std::false_type{});
+      if (pind < 0) break;
+      const int pq = pind - s;
       if (lane == 0) { label[pind] = 3; t_flat[n_flat] = pind; }
       n_flat++;
       smallest++;
@@ -513,7 +559,7 @@ __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView
       int back, fwd;
       neighbour_span(gap, pq, back, fwd);
       if (lane == 0) picked.or_window(pq - back, (2u << (back + fwd)) - 1u);
-      suppress(pind - back, pind + fwd);
+      suppress(pind - back, back + fwd + 1, ~0u);
       wave_sync();
     }
     wave_sync();
