@@ -378,6 +378,10 @@ __device__ __forceinline__ void neighbour_span(const RingBits& gap, int q, int& 
 // wave-wide extremum of a 32-bit word, same six DPP steps as wave_extremum_u64
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned dpp_u32(unsigned k) { return (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, CTRL, ROW_MASK, 0xf, false); }
+// every lane takes the value of the lane above it (lane 63: 0)
+__device__ __forceinline__ float dpp_wave_shl1(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
 template <bool MAX>
 __device__ __forceinline__ unsigned wave_extremum_u32(unsigned k) {
   auto pick = [](unsigned a, unsigned c) { return MAX ? (a > c ? a : c) : (a < c ? a : c); };
@@ -780,8 +784,8 @@ constexpr int kVoxMaxPoints = 65535;                // the first point of a run 
 constexpr int kVoxSmallPoints = 4096;
 
 template <int kVoxWaves, int kVoxRunsPerWave>
-__global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBatchView v, float4* __restrict__ staging, int* __restrict__ m_out,
-                                                                          int* __restrict__ flags, int only_escalated) {
+__global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBatchView v, float4* __restrict__ staging, float4* __restrict__ run_sums,
+                                                                          int* __restrict__ m_out, int* __restrict__ flags, int only_escalated) {
   constexpr int kVoxMaxRuns = kVoxWaves * kVoxRunsPerWave;
   constexpr int kThreads = 64 * kVoxWaves;
   __shared__ unsigned long long s_run[kVoxMaxRuns];           // [coords 3 x 14 bits, later the voxel index : 42][first point : 16][length - 1 : 6]
@@ -834,14 +838,34 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
       const int q0 = __shfl_up(c0, 1), q1 = __shfl_up(c1, 1), q2 = __shfl_up(c2, 1);
       const bool head = valid && (lane == 0 || c0 != q0 || c1 != q1 || c2 != q2);
       const unsigned long long heads = __ballot(head), live = __ballot(valid);
+      int len = 0;                                                       // of the run this lane opens
+      int slot = 0;
       if (head) {
         const unsigned long long above = heads & ~((2ull << lane) - 1ull);             // heads in higher lanes
         const int end = above ? __ffsll((long long)above) - 1 : __popcll(live);
-        const int slot = n_runs + __popcll(heads & ((1ull << lane) - 1ull));
+        slot = n_runs + __popcll(heads & ((1ull << lane) - 1ull));
+        len = end - lane;
         if (slot < kVoxRunsPerWave)
           s_run[wave * kVoxRunsPerWave + slot] = ((unsigned long long)(unsigned)(c0 + 8192) << 50) | ((unsigned long long)(unsigned)(c1 + 8192) << 36) |
                                                  ((unsigned long long)(unsigned)(c2 + 8192) << 22) | ((unsigned long long)(unsigned)k << 6) |
-                                                 (unsigned long long)(end - lane - 1);
+                                                 (unsigned long long)(len - 1);
+      }
+      // The run's points summed in arrival order while they are in registers: head lane h adds the values of lanes
+      // h + 1, h + 2, ... one per step, every lane's value moving one lane down per step on the DPP network
+      // (wave_shl:1).  A voxel with ONE run (93 % of a less-flat list's voxels) then needs no second look at its points;
+      // the accumulators start from +0 like CentroidPoint's (0 + x, so that a lone -0 comes out as +0), and an inactive
+      // step adds +0, which never changes a sum that started that way.
+      {
+        const float4 p = pp[u];
+        float sx = 0.f + p.x, sy = 0.f + p.y, sz = 0.f + p.z, st = 0.f + p.w;
+        float vx = p.x, vy = p.y, vz = p.z, vt = p.w;
+        const int longest = (int)wave_extremum_u32<true>((unsigned)len);
+        for (int e = 1; e < longest; e++) {
+          vx = dpp_wave_shl1(vx); vy = dpp_wave_shl1(vy); vz = dpp_wave_shl1(vz); vt = dpp_wave_shl1(vt);
+          const bool on = e < len;
+          sx += on ? vx : 0.f; sy += on ? vy : 0.f; sz += on ? vz : 0.f; st += on ? vt : 0.f;
+        }
+        if (head && slot < kVoxRunsPerWave) run_sums[v.off[b] + k0 + slot] = make_float4(sx, sy, sz, st);     // a slice has no more runs than points
       }
       n_runs += __popcll(heads);
     }
@@ -963,28 +987,30 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
 #if MSFL_VOX_EXP == 3
   if (tid == 0) { flags[b] = 0; m_out[b] = 0; } return;
 #endif
-  // Small voxels: one thread each.  A voxel close to the sensor can hold hundreds of points (a 0.4 m cube on the ground
-  // two metres out takes ~60 points of every ring that crosses it): a single thread would chain that many dependent loads
-  // while its workgroup, the only one on the CU, waits.  Voxels with more than kBigVoxel points are therefore collected
-  // (s_hist is free now) and summed by a whole wavefront each: one coalesced load per run, then the same sequential
-  // f32 additions on every lane through broadcasts.
+  // Every voxel starts from its first run's sum (phase 1); only later runs (7 % of the voxels of a less-flat list have
+  // any) are read again and added point by point.  Small voxels: one thread each.  A voxel close to the sensor can hold
+  // hundreds of points (a 0.4 m cube on the ground two metres out takes ~60 points of every ring that crosses it): a
+  // single thread would chain that many dependent loads while its workgroup, the only one on the CU, waits.  Voxels with
+  // more than kBigVoxel points after their first run are therefore collected (s_hist is free now) and summed by a whole
+  // wavefront each: one coalesced load per run, then the same sequential f32 additions on every lane through broadcasts.
   constexpr int kBigVoxel = 24;
-  unsigned short* big_list = &s_hist[0][0];                 // up to kVoxWaves * 256 entries
+  // s_hist is free now: [0, kMultiCap) lists the voxels with more than one run, the rest the big ones among them
+  constexpr int kMultiCap = kVoxWaves * 192, kBigCap = kVoxWaves * 64;
+  unsigned short* multi_list = &s_hist[0][0];
+  unsigned short* big_list = multi_list + kMultiCap;
+  __shared__ int s_nbig;
   __syncthreads();                                           // every thread has read m = s_total
-  if (tid == 0) s_total = 0;
+  if (tid == 0) { s_total = 0; s_nbig = 0; }
   __syncthreads();
-  for (int r = tid; r < m; r += kThreads) {
-    const int j0 = heads_at[r], j1 = (r + 1 < m) ? (int)heads_at[r + 1] : E;
+  const float4* sums = run_sums + v.off[b];
+  auto sum_of = [&](int id) { return sums[(id / kVoxRunsPerWave) * seg + (id % kVoxRunsPerWave)]; };    // run id -> slice start + slot
+  // the later runs of voxel r added point by point to (sx, sy, sz, st); returns the voxel's point count
+  auto later_runs = [&](int j0, int j1, float& sx, float& sy, float& sz, float& st) {
     int total = 0;
-    for (int j = j0; j < j1; j++) total += (int)(s_run[s_ord[cur][j]] & 0x3fu) + 1;
-    if (total > kBigVoxel) {
-      const int at = atomicAdd(&s_total, 1);
-      if (at < kVoxWaves * 256) { big_list[at] = (unsigned short)r; continue; }        // list full: summed by this thread after all
-    }
-    float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
-    for (int j = j0; j < j1; j++) {
+    for (int j = j0 + 1; j < j1; j++) {
       const unsigned long long rec = s_run[s_ord[cur][j]];
       const int k = (int)((rec >> 6) & 0xffffu), len = (int)(rec & 0x3fu) + 1;
+      total += len;
       for (int e = 0; e < len; e += 4) {                                // four loads in flight, added in arrival order
         const float4 p0 = vb_point(v, b, k + e), p1 = vb_point(v, b, k + min(e + 1, len - 1)), p2 = vb_point(v, b, k + min(e + 2, len - 1)),
                      p3 = vb_point(v, b, k + min(e + 3, len - 1));
@@ -994,21 +1020,58 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
         if (e + 3 < len) { sx += p3.x; sy += p3.y; sz += p3.z; st += p3.w; }
       }
     }
+    return total;
+  };
+  // pass 1: single-run voxels are done with one 16-byte load; the others queue up, so that no lane waits on a
+  // neighbour's chain of dependent point loads five voxels in a row
+  for (int r = tid; r < m; r += kThreads) {
+    const int j0 = heads_at[r], j1 = (r + 1 < m) ? (int)heads_at[r + 1] : E;
+    const int id0 = s_ord[cur][j0];
+    const float4 first = sum_of(id0);
+    const int len0 = (int)(s_run[id0] & 0x3fu) + 1;
+    float sx = first.x, sy = first.y, sz = first.z, st = first.w;
+    int total = len0;
+    if (j1 - j0 > 1) {
+      const int at = atomicAdd(&s_total, 1);
+      if (at < kMultiCap) { multi_list[at] = (unsigned short)r; continue; }
+      total += later_runs(j0, j1, sx, sy, sz, st);                       // list full: finished here after all
+    }
     const float c = (float)total;
     out[r] = make_float4(sx / c, sy / c, sz / c, st / c);
   }
   __syncthreads();
-  const int n_big = min(s_total, kVoxWaves * 256);
+  // pass 2: the multi-run voxels, one thread each; the big ones move on to the wavefront-per-voxel pass
+  const int n_multi = min(s_total, kMultiCap);
+  for (int q = tid; q < n_multi; q += kThreads) {
+    const int r = multi_list[q];
+    const int j0 = heads_at[r], j1 = (r + 1 < m) ? (int)heads_at[r + 1] : E;
+    const int id0 = s_ord[cur][j0];
+    const int len0 = (int)(s_run[id0] & 0x3fu) + 1;
+    int later = 0;
+    for (int j = j0 + 1; j < j1; j++) later += (int)(s_run[s_ord[cur][j]] & 0x3fu) + 1;
+    if (later > kBigVoxel) {
+      const int at = atomicAdd(&s_nbig, 1);
+      if (at < kBigCap) { big_list[at] = (unsigned short)r; continue; }
+    }
+    const float4 first = sum_of(id0);
+    float sx = first.x, sy = first.y, sz = first.z, st = first.w;
+    const float c = (float)(len0 + later_runs(j0, j1, sx, sy, sz, st));
+    out[r] = make_float4(sx / c, sy / c, sz / c, st / c);
+  }
+  __syncthreads();
+  const int n_big = min(s_nbig, kBigCap);
   for (int q = wave; q < n_big; q += kVoxWaves) {
     const int r = big_list[q];
-    const int j0 = heads_at[r], j1 = (r + 1 < m) ? (int)heads_at[r + 1] : E;
-    float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
-    int total = 0;
+    const int j0 = heads_at[r], j1 = (r + 1 < m) ? (int)heads_at[r + 1] : E;     // j1 - j0 >= 2 here
+    const int id0 = s_ord[cur][j0];
+    const float4 first = sum_of(id0);
+    float sx = first.x, sy = first.y, sz = first.z, st = first.w;
+    int total = (int)(s_run[id0] & 0x3fu) + 1;
     // software pipeline over the runs: the next run's points are loading while this one is summed
-    unsigned long long rec = s_run[s_ord[cur][j0]];
+    unsigned long long rec = s_run[s_ord[cur][j0 + 1]];
     int k = (int)((rec >> 6) & 0xffffu), len = (int)(rec & 0x3fu) + 1;
     float4 p = vb_point(v, b, k + min(lane, len - 1));
-    for (int j = j0; j < j1; j++) {
+    for (int j = j0 + 1; j < j1; j++) {
       const float4 pc = p; const int lc = len;
       if (j + 1 < j1) {
         rec = s_run[s_ord[cur][j + 1]];
