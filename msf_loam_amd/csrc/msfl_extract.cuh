@@ -30,6 +30,7 @@ struct ExtractParams {
   double curvature_threshold;   // compared as double against the f32 curvature (:275, :312)
   double neighbor_gap_sq;       // compared as double against the f32 squared gap (:293)
   int sectors, max_sharp, max_less_sharp, max_flat;
+  float min_range_sq;           // the smallest f32 s with (double)sqrtf(s) >= min_range (host: extract_params); 0 when nothing is too close
 };
 
 #ifndef MSFL_STREAM_BLOCK
@@ -57,18 +58,22 @@ struct ExtractView {
   int* ring_cnt;               // n_scans x kMaxRings x 4
 };
 
-__device__ __forceinline__ bool point_valid(float4 p, double min_range) {
-  // RemoveInvalidPointsFromCloud: getVector3fMap().norm() < min_range || !finite
-  const float nrm = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
-  return !((double)nrm < min_range || !isfinite(p.x) || !isfinite(p.y) || !isfinite(p.z));
+__device__ __forceinline__ bool point_valid(float4 p, float min_range_sq) {
+  // RemoveInvalidPointsFromCloud: getVector3fMap().norm() < min_range || !finite.  sqrtf is correctly rounded and
+  // monotone, so "(double)sqrtf(s) < min_range" is "s < min_range_sq" for the f32 threshold the host searched for
+  // (no square root, no f64 compare per point); a finite s has finite coordinates, so the finite test only runs when
+  // s overflowed or is NaN
+  const float s = p.x * p.x + p.y * p.y + p.z * p.z;
+  bool valid = !(s < min_range_sq);
+  if (!(fabsf(s) < INFINITY)) valid = valid && isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+  return valid;
 }
 
 // lanes of the wave that are valid and carry the same ring id (< 128): seven ballots, one per ring bit,
 // instead of one loop iteration per distinct ring in the group (a 64-beam driver interleaves all rings)
-__device__ __forceinline__ unsigned long long same_ring_lanes(bool valid, int r) {
+__device__ __forceinline__ unsigned long long same_ring_lanes(bool valid, int r, int nbits) {
   unsigned long long m = __ballot(valid);
-#pragma unroll
-  for (int bit = 0; bit < 7; bit++) {
+  for (int bit = 0; bit < nbits; bit++) {               // nbits: those of the scan's highest ring id (4 on a VLP-16), uniform
     const bool set = (r >> bit) & 1;
     const unsigned long long b = __ballot(valid && set);
     m &= set ? b : ~b;
@@ -84,8 +89,8 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
   __shared__ int s_off[kMaxRings + 1];
   __shared__ int s_wrap[kMaxRings];
   __shared__ int s_cur[16][kMaxRings];      // pass A: population of (wave, ring); pass B: write cursor
-  __shared__ int s_first[16], s_badw[16];
-  __shared__ int s_flag[2];
+  __shared__ int s_first[16], s_badw[16], s_rmax[16];
+  __shared__ int s_flag[3];
   __shared__ double s_start_ori;
   __shared__ double s_lasta[16][kMaxRings];   // pass B: raw angle of the last point of (wave, ring) so far; NaN = none yet
   __shared__ double s_firsta[16][kMaxRings];  // raw angle of the first point of (wave, ring)
@@ -99,7 +104,7 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
   const int slice = ((n + 15) / 16 + 63) & ~63;            // multiple of 64: a 64-point group never straddles two waves
   const int w0 = min(wave * slice, n), w1 = min(w0 + slice, n);
   // ---- pass A: populations, first valid point, ring check ----
-  int first = 0x7fffffff, bad = 0;
+  int first = 0x7fffffff, bad = 0, rmax = 0;
   // four 64-point groups per iteration with their loads issued up front: one workgroup per CU keeps 16 wavefronts
   // there, and one 16-byte load per lane in flight is far from what HBM needs to stay busy
 #ifndef MSFL_PREP_GROUPS
@@ -122,22 +127,23 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
       bool valid = false;
       int r = -1;
       if (i < w1) {
-        valid = point_valid(pp[u], prm.min_range);
+        valid = point_valid(pp[u], prm.min_range_sq);
         if (valid) { r = rr[u]; if (r >= kMaxRings) { bad = 1; valid = false; } }   // CHECK_LT(point.ring, 128), :136
       }
       const unsigned long long any_valid = __ballot(valid);
       if (any_valid && first == 0x7fffffff) first = g + (__ffsll((long long)any_valid) - 1);
-      const unsigned long long m = same_ring_lanes(valid, r);
-      if (valid && lane == __ffsll((long long)m) - 1) s_cur[wave][r] += __popcll(m);     // one leader per distinct ring
+      if (valid) { atomicAdd(&s_cur[wave][r], 1); rmax = max(rmax, r); }       // LDS atomic: one instruction instead of the ballot match
     }
   }
   bad = __any(bad) ? 1 : 0;
-  if (lane == 0) { s_first[wave] = first; s_badw[wave] = bad; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) rmax = max(rmax, __shfl_xor(rmax, o));
+  if (lane == 0) { s_first[wave] = first; s_badw[wave] = bad; s_rmax[wave] = rmax; }
   __syncthreads();
   if (tid == 0) {
-    int f = 0x7fffffff, bd = 0;
-    for (int w = 0; w < 16; w++) { f = min(f, s_first[w]); bd |= s_badw[w]; }
-    s_flag[0] = f; s_flag[1] = bd;
+    int f = 0x7fffffff, bd = 0, rm = 0;
+    for (int w = 0; w < 16; w++) { f = min(f, s_first[w]); bd |= s_badw[w]; rm = max(rm, s_rmax[w]); }
+    s_flag[0] = f; s_flag[1] = bd; s_flag[2] = 32 - __clz(rm | 1);          // bits of the highest ring id present
   }
   // ring totals -> s_off (exclusive), then (wave, ring) cursors
   if (tid < kMaxRings) {
@@ -172,6 +178,7 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
   }
   __syncthreads();
   const int N = s_off[kMaxRings];
+  const int ring_bits = __builtin_amdgcn_readfirstlane(s_flag[2]);
   const double start_ori = s_start_ori;
   const double two_pi = 2 * 3.14159265358979323846;
   float4* out_pts = v.full_pts + o;
@@ -199,11 +206,11 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
     int r = -1;
     bool valid = false;
     if (i < w1) {
-      valid = point_valid(p, prm.min_range);
+      valid = point_valid(p, prm.min_range_sq);
       if (valid) r = rr[u];
     }
     int dst = 0;
-    const unsigned long long m = same_ring_lanes(valid, r);
+    const unsigned long long m = same_ring_lanes(valid, r, ring_bits);
     const unsigned long long below = m & ((1ull << lane) - 1ull);
     double a = 0.0;
     if (valid) {

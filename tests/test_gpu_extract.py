@@ -51,6 +51,37 @@ def test_batch_ragged_bit_exact(gpu, oracle):
         _check(f, oracle.extract_features(p, r))
 
 
+def test_minimum_range_edge_is_the_reference_compare(gpu, oracle):
+    """Invalid-point removal is `norm() < min_range` on the f32 norm, compared as double (msf_loam_node.cc:85-111).  The
+    kernel tests the squared norm against a threshold the host searches for; points whose norm sits within a few ulps of
+    the range on either side, a squared norm that overflows (finite coordinates: the reference keeps the point) and
+    non-finite coordinates must be kept / dropped exactly as the oracle does, for several ranges."""
+    pts, ring, _, _ = common.scans(1)[0]
+    rng = np.random.default_rng(77)
+    for min_range in (0.3, 0.30000001192092896, 1.0, 2.5, 1e-3):
+        p = pts.copy()
+        pick = rng.choice(len(p), 4000, replace=False)
+        d = p[pick, :3].astype(np.float64)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        scale = np.float32(min_range) * (1.0 + rng.integers(-6, 7, len(pick)) * 2.0 ** -24)      # a few ulps around the range
+        p[pick, :3] = (d * scale[:, None]).astype(np.float32)
+        p[pick[:3], 0] = [np.inf, -np.inf, np.nan]
+        p[pick[3], :3] = [2e19, 1.0, 1.0]                                 # x*x overflows f32: the norm is inf, not "< min_range"
+        fo = oracle.extract_features(p, ring, min_range=min_range)
+        prm = capi.default_params()
+        prm.min_range = min_range
+        h = capi.Handle(0, params=prm)
+        try:
+            f = h.extract_features(p, ring)
+        finally:
+            h.close()
+        assert f["rc"] == fo["rc"] == 0
+        n_near = int(np.sum(np.abs(np.linalg.norm(p[pick[4:], :3].astype(np.float64), axis=1) / min_range - 1) < 1e-6))
+        assert n_near > 3000 and 0 < len(pts) - len(fo["full"]) < len(pick)      # the edge really splits the planted points
+        assert np.array_equal(f["ring"], fo["ring"]) and np.array_equal(f["full"][:, :3], fo["full"][:, :3])
+        assert np.array_equal(f["label"], fo["label"])
+
+
 def test_hand_made_ties_and_gap_breaks(gpu, oracle):
     n = 300
     pts = np.zeros((n, 4), np.float32)
