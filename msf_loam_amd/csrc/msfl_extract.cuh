@@ -586,17 +586,26 @@ __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView
   if (lane == 0) { cnt_out[0] = n_sharp; cnt_out[1] = n_ls; cnt_out[2] = n_flat; cnt_out[3] = n_lf; }
 }
 
-__global__ void __launch_bounds__(256) extract_compact_kernel(ExtractView v, const double* __restrict__ extrinsic) {
+constexpr int kCompactThreads = 1024;     // a less-flat list is ~20 k entries per scan: 256 threads walked it in 80 dependent rounds
+
+__global__ void __launch_bounds__(kCompactThreads) extract_compact_kernel(ExtractView v, const double* __restrict__ extrinsic) {
+  static_assert(kMaxRings == 128, "two rings per lane in the prefix below");
   __shared__ int s_pref[4][kMaxRings + 1];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ int s_tab[kMaxRings + 1];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int o = v.off[b];
   const int* cnt = v.ring_cnt + (size_t)b * kMaxRings * 4;
   const int* tab = v.ring_tab + b * (kMaxRings + 1);
   const bool ok = (v.status[b] == 0);
-  if (tid < 4) {
-    int run = 0;
-    for (int r = 0; r < kMaxRings; r++) { s_pref[tid][r] = run; run += ok ? cnt[r * 4 + tid] : 0; }
-    s_pref[tid][kMaxRings] = run;
+  if (tid >= 512 && tid - 512 <= kMaxRings) s_tab[tid - 512] = tab[tid - 512];
+  if (wave < 4) {                                  // list `wave`: exclusive prefix of its 128 per-ring counts, two rings per lane
+    const int c0 = ok ? cnt[(2 * lane) * 4 + wave] : 0, c1 = ok ? cnt[(2 * lane + 1) * 4 + wave] : 0;
+    int incl = c0 + c1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+    s_pref[wave][2 * lane] = incl - c0 - c1;
+    s_pref[wave][2 * lane + 1] = incl - c1;
+    if (lane == 63) s_pref[wave][kMaxRings] = incl;
   }
   __syncthreads();
   if (tid == 0) {
@@ -612,10 +621,22 @@ __global__ void __launch_bounds__(256) extract_compact_kernel(ExtractView v, con
     // one flat loop over the output positions; the owning ring comes from a 7-step search in the LDS prefix
     // (instead of 128 per-ring loops, most of them over empty or 2-entry lists)
     const int total = s_pref[L][kMaxRings];
-    for (int k = tid; k < total; k += 256) {
-      int lo = 0, hi = kMaxRings;                    // largest r with s_pref[L][r] <= k and a non-empty list
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[L][mid] <= k) lo = mid; else hi = mid; }
-      outs[L][k] = tmp[tab[lo] + (k - s_pref[L][lo])];
+    // four entries per thread and round: the searches, then the four loads together, then the stores (one entry per
+    // round left every round waiting on its own load)
+    for (int k0 = tid; k0 < total; k0 += 4 * kCompactThreads) {
+      int src[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = min(k0 + u * kCompactThreads, total - 1);
+        int lo = 0, hi = kMaxRings;                    // largest r with s_pref[L][r] <= k and a non-empty list
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[L][mid] <= k) lo = mid; else hi = mid; }
+        src[u] = s_tab[lo] + (k - s_pref[L][lo]);
+      }
+      int val[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) val[u] = tmp[src[u]];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int k = k0 + u * kCompactThreads; if (k < total) outs[L][k] = val[u]; }
     }
   }
   // TransformPointCloudInPlace x5 (:367-371): the five clouds are gathers of the full cloud
@@ -623,7 +644,7 @@ __global__ void __launch_bounds__(256) extract_compact_kernel(ExtractView v, con
     const pose7 T = load_pose(extrinsic);
     const int N = v.n_full[b];
     float4* c = v.full_pts + o;
-    for (int i = tid; i < N; i += 256) {
+    for (int i = tid; i < N; i += kCompactThreads) {
       const float4 p = c[i];
       const float3 t = transform_point_f32(T, p.x, p.y, p.z);
       c[i] = make_float4(t.x, t.y, t.z, p.w);
