@@ -51,7 +51,6 @@ struct ExtractView {
   int* n_full; int* n_sharp; int* n_less_sharp; int* n_flat; int* n_less_flat;
   int* status;
   // scratch
-  double* rel;                 // n_total: raw relative angle per output point
   uint8_t* gap;                // n_total: 1 if |p[i+1]-p[i]|^2 > neighbor_gap_sq
   int* ring_tab;               // n_scans x (kMaxRings + 1): ring start offsets (scan-local)
   int* tmp_idx;                // 4 x n_total: per-ring lists before compaction
@@ -94,6 +93,9 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
   __shared__ double s_start_ori;
   __shared__ double s_lasta[16][kMaxRings];   // pass B: raw angle of the last point of (wave, ring) so far; NaN = none yet
   __shared__ double s_firsta[16][kMaxRings];  // raw angle of the first point of (wave, ring)
+  __shared__ double s_pre_last[kMaxRings];    // early-wrap pre-pass: angle of the ring's last point so far (NaN = none)
+  __shared__ int s_pre_cnt[kMaxRings];        //                       points of the ring so far
+  __shared__ int s_early[kMaxRings];          // output index of the ring's wrap point if it lies in the cloud's first 256 points
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int o = v.off[b];
   const int n = v.off[b + 1] - o;
@@ -183,12 +185,51 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
   const double two_pi = 2 * 3.14159265358979323846;
   float4* out_pts = v.full_pts + o;
   uint16_t* out_ring = v.full_ring + o;
+  // relative angle of a point (:139-142): fmod(a, 2 pi) with a = ori - start_ori + 2 pi in [0, 4 pi]: fmod is exact and so is
+  // a - 2 pi for 2 pi <= a <= 4 pi (Sterbenz), so two conditional subtractions give the same bits
+  auto rel_angle = [&](const float4 p) __attribute__((always_inline)) {
+    const double ori = -atan2((double)p.y, (double)p.x);
+    double a = ori - start_ori + two_pi;
+    if (a >= two_pi) a -= two_pi;
+    if (a >= two_pi) a -= two_pi;
+    return a;
+  };
+  // ---- early wraps.  A ring whose first point lies just BEHIND the cloud's first point in azimuth starts at an angle just
+  //      below 2 pi and wraps at its second point: that is about half the rings of a spinning lidar, and every point of such a
+  //      ring takes the +2 pi time.  Found after the scatter, that meant rewriting the time word of half the cloud (a 4-byte
+  //      write into a 16-byte point = a read-modify-write of the whole line, plus the parked candidates).  So wavefront 0 runs
+  //      the wrap test over the first 256 points of the cloud first, with exactly the arithmetic of the pass below; pass B
+  //      then stores the final time for everything behind a wrap point found here, and the fix-up only serves later wraps ----
+  if (tid < kMaxRings) { s_pre_last[tid] = __longlong_as_double(0x7ff8000000000000ll); s_pre_cnt[tid] = 0; s_early[tid] = 0x7fffffff; }
+  __syncthreads();
+  if (wave == 0) {
+    const int pre_end = min(w1, 256);
+    for (int g = 0; g < pre_end; g += 64) {
+      const int i = g + lane;
+      float4 p = make_float4(0, 0, 0, 0);
+      int r = -1;
+      bool valid = false;
+      if (i < pre_end) { p = in[i]; valid = point_valid(p, prm.min_range_sq); if (valid) r = in_ring[i]; }
+      const unsigned long long m = same_ring_lanes(valid, r, ring_bits);
+      const unsigned long long below = m & ((1ull << lane) - 1ull);
+      const double a = valid ? rel_angle(p) : 0.0;
+      const int pl = below ? 63 - __clzll((long long)below) : lane;
+      double a_prev = __shfl(a, pl);
+      if (valid) {
+        const int seen = s_pre_cnt[r];                         // every lane of a ring reads before its last lane writes
+        bool has_prev = below != 0;
+        if (!has_prev) { a_prev = s_pre_last[r]; has_prev = !isnan(a_prev); }
+        if ((m >> lane) == 1ull) { s_pre_last[r] = a; s_pre_cnt[r] = seen + __popcll(m); }
+        if (has_prev && a < a_prev) atomicMin(&s_early[r], s_off[r] + seen + __popcll(below));
+      }
+    }
+  }
+  __syncthreads();
   // ---- pass B: stable split into rings, every wave in its own slice, driver order.  The wrap test of the reference
   //      (`relative_angle < last_relative_angles[ring]`, :145-149: from the first such point on a ring gets +2 pi) compares a
   //      point with its predecessor ON ITS RING, which is the previous same-ring lane of the group, or the last same-ring
   //      point this wave has seen (LDS), or the last one of an earlier wave (fixed up after the pass): the f64 raw angles
-  //      never go to memory.  Both candidate times are produced here; the wrapped one waits in `t1` ----
-  float* t1 = reinterpret_cast<float*>(v.rel + o);
+  //      never go to memory ----
   for (int g0 = w0; g0 < w1; g0 += 64 * kGroups) {
     float4 pp[kGroups]; int rr[kGroups];
 #pragma unroll
@@ -217,12 +258,7 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
       const int cur = s_cur[wave][r];                        // every lane of a ring reads the cursor ...
       dst = cur + __popcll(below);
       if (below == 0) s_cur[wave][r] = cur + __popcll(m);    // ... before its leader advances it
-      const double ori = -atan2((double)p.y, (double)p.x);                 // :139
-      // fmod(a, 2 pi) with a = ori - start_ori + 2 pi in [0, 4 pi]: fmod is exact and so is a - 2 pi for
-      // 2 pi <= a <= 4 pi (Sterbenz), so two conditional subtractions give the same bits (:142)
-      a = ori - start_ori + two_pi;
-      if (a >= two_pi) a -= two_pi;
-      if (a >= two_pi) a -= two_pi;
+      a = rel_angle(p);
     }
     // predecessor on the ring inside this group: the highest same-ring lane below this one
     const int pl = below ? 63 - __clzll((long long)below) : lane;
@@ -236,10 +272,11 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
       }
       if ((m >> lane) == 1ull) s_lasta[wave][r] = a;         // last lane of the ring in this group (after the leader's read)
       if (has_prev && a < a_prev) atomicMin(&s_wrap[r], dst);
-      const float t0 = (float)(a / two_pi * prm.scan_period);                        // :151
-      t1[dst] = (float)((a + two_pi) / two_pi * prm.scan_period);
-      out_pts[dst] = make_float4(p.x, p.y, p.z, t0);
-      out_ring[dst] = (uint16_t)r;
+      // :151; behind a wrap point the angle carries +2 pi.  No ring id is stored here: a ring's ids are one constant over its
+      // output range (filled below with full-width stores; 2-byte stores scattered over 16 ring ranges were written to
+      // memory as partial lines, PMC: 0.83 GB written per 1 024 scans for 0.43 GB of output)
+      const double aw = dst >= s_early[r] ? a + two_pi : a;
+      out_pts[dst] = make_float4(p.x, p.y, p.z, (float)(aw / two_pi * prm.scan_period));
     }
     }
   }
@@ -263,11 +300,21 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
     }
   }
   __syncthreads();
-  // relative time (stored in both `time` and `intensity`, :152-153): from a ring's wrap point on, the +2 pi candidate
-  for (int i = tid; i < N; i += 1024) {
-    const int r = out_ring[i];
-    if (i >= s_wrap[r]) out_pts[i].w = t1[i];
+  // relative time (stored in both `time` and `intensity`, :152-153): from a ring's wrap point on, the +2 pi candidate.  What
+  // lies behind an EARLY wrap point has it already (s_wrap == s_early there); a later wrap (the sweep passing the start
+  // direction again at the end of the scan) re-derives the angle of the few points behind it from their coordinates,
+  // which are stored unchanged, with the same arithmetic as the pass above
+  for (int r = wave; r < kMaxRings; r += 16) {
+    const int lo = s_wrap[r], hi = min(s_early[r], s_off[r + 1]);
+    if (lo >= hi) continue;                                  // no wrap on this ring (lo = INT_MAX), or an early one
+    for (int i = lo + lane; i < hi; i += 64) {
+      const float4 p = out_pts[i];
+      out_pts[i].w = (float)((rel_angle(p) + two_pi) / two_pi * prm.scan_period);
+    }
   }
+  // ring ids: constant runs
+  for (int r = wave; r < kMaxRings; r += 16)
+    for (int i = s_off[r] + lane; i < s_off[r + 1]; i += 64) out_ring[i] = (uint16_t)r;
   if (tid == 0) v.n_full[b] = N;
 }
 
