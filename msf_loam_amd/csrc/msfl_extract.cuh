@@ -719,9 +719,10 @@ __device__ __forceinline__ float4 vb_point(const VoxelBatchView& v, int b, int k
 }
 
 // also: n_valid[b] (input to the slot scan) and max_cells[0] = the largest voxel count of any cloud (sort key width)
-__global__ void __launch_bounds__(256) voxel_batch_desc_kernel(VoxelBatchView v, VoxelCloudDesc* __restrict__ desc, int* __restrict__ n_valid,
+constexpr int kVoxDescThreads = 1024;       // one workgroup per cloud: a 64-beam less-flat list is ~100 k points
+__global__ void __launch_bounds__(kVoxDescThreads) voxel_batch_desc_kernel(VoxelBatchView v, VoxelCloudDesc* __restrict__ desc, int* __restrict__ n_valid,
                                                                 int* __restrict__ max_cells) {
-  __shared__ float s_mn[4][3], s_mx[4][3];
+  __shared__ float s_mn[kVoxDescThreads / 64][3], s_mx[kVoxDescThreads / 64][3];
   const int b = blockIdx.x;
   const int cap = v.off[b + 1] - v.off[b];
   const int n = v.count ? min(max(v.count[b], 0), cap) : cap;
@@ -729,7 +730,7 @@ __global__ void __launch_bounds__(256) voxel_batch_desc_kernel(VoxelBatchView v,
   __shared__ int s_nonfinite;
   if (threadIdx.x == 0) s_nonfinite = 0;
   __syncthreads();
-  for (int k = threadIdx.x; k < n; k += 256) {
+  for (int k = threadIdx.x; k < n; k += kVoxDescThreads) {
     const float4 p = vb_point(v, b, k);
     if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
       mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
@@ -751,7 +752,7 @@ __global__ void __launch_bounds__(256) voxel_batch_desc_kernel(VoxelBatchView v,
     long long cells = 1;
     for (int a = 0; a < 3; a++) {
       float lo = s_mn[0][a], hi = s_mx[0][a];
-      for (int w = 1; w < 4; w++) { lo = fminf(lo, s_mn[w][a]); hi = fmaxf(hi, s_mx[w][a]); }
+      for (int w = 1; w < kVoxDescThreads / 64; w++) { lo = fminf(lo, s_mn[w][a]); hi = fmaxf(hi, s_mx[w][a]); }
       if (!(lo <= hi)) { d.min_b[a] = 0; d.div_b[a] = 1; if (n > 0) d.bad = 2; continue; }       // no finite point
       d.min_b[a] = (int)floorf(lo * v.inv_leaf);
       d.div_b[a] = (int)floorf(hi * v.inv_leaf) - d.min_b[a] + 1;
@@ -765,28 +766,54 @@ __global__ void __launch_bounds__(256) voxel_batch_desc_kernel(VoxelBatchView v,
   }
 }
 
-// one thread per VALID point of the batch: slot e of the compacted numbering belongs to cloud
-// b = upper_bound(in_off, e) - 1 at position k = e - in_off[b]
-__global__ void __launch_bounds__(256) voxel_batch_key_kernel(VoxelBatchView v, const VoxelCloudDesc* __restrict__ desc,
-                                                               const int* __restrict__ in_off, int n_valid, int cell_bits, int idx_bits,
-                                                               unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
-                                                               float4* __restrict__ pts_c) {
+// ---- device-wide form for batches with a cloud the LDS form cannot hold (a 64-beam less-flat list is ~100 k points) ----
+// It sorts RUNS, not points: points arrive in ring / azimuth order, a run of consecutive points of one voxel is one
+// (key, run number) pair, there are 4-5 x fewer runs than points, and a stable sort of the runs by (cloud, voxel) keeps a
+// voxel's runs in arrival order.  Round 1 sorted every point (five 8-bit passes over 64-bit keys for 125 M points of
+// 1 250 64-beam scans, then a gather of the points into key order): 9.7 ms of that configuration's 19.5.
+//   head kernel        slot e of the compacted valid-point numbering (cloud b = upper_bound(in_off, e) - 1, position
+//                      k = e - in_off[b]): voxel index of the point and of its predecessor in the cloud -> head flag
+//   (scan)             run numbers in arrival order
+//   run kernel         per head: key = cloud | voxel index [| run number in the low bits], first slot of the run
+//   (stable radix sort of the runs, voxel heads, scan)
+//   centroid kernel    one thread per voxel: its runs in order, their points in order, f32 sums like CentroidPoint
+__device__ __forceinline__ unsigned long long vb_cell(const VoxelBatchView& v, const VoxelCloudDesc& d, const float4 p) {
+  const int i0 = (int)(floorf(p.x * v.inv_leaf) - (float)d.min_b[0]);
+  const int i1 = (int)(floorf(p.y * v.inv_leaf) - (float)d.min_b[1]);
+  const int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)d.min_b[2]);
+  return (unsigned long long)((long long)i0 + (long long)i1 * d.div_b[0] + (long long)i2 * d.div_b[0] * (long long)d.div_b[1]);
+}
+
+__global__ void __launch_bounds__(256) voxel_batch_head_kernel(VoxelBatchView v, const VoxelCloudDesc* __restrict__ desc,
+                                                                const int* __restrict__ in_off, int n_valid, int* __restrict__ flag) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_valid) return;
   const int b = find_scan_off_wave(in_off, v.n_clouds, e);
   const int k = e - in_off[b];
   const VoxelCloudDesc d = desc[b];
-  const float4 p = vb_point(v, b, k);
-  const int i0 = (int)(floorf(p.x * v.inv_leaf) - (float)d.min_b[0]);
-  const int i1 = (int)(floorf(p.y * v.inv_leaf) - (float)d.min_b[1]);
-  const int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)d.min_b[2]);
-  const unsigned long long cell = (unsigned long long)((long long)i0 + (long long)i1 * d.div_b[0] + (long long)i2 * d.div_b[0] * (long long)d.div_b[1]);
-  // idx_bits > 0: the slot number rides in the low bits of the key and the (stable) radix sort only looks at the bits
-  // above it, so the sort moves 8 bytes per element and pass instead of 12 (key + value)
+  flag[e] = (k == 0 || vb_cell(v, d, vb_point(v, b, k)) != vb_cell(v, d, vb_point(v, b, k - 1))) ? 1 : 0;
+}
+
+// run_first[r] = first slot of run r (runs numbered in arrival order), run_first[n_runs] = n_valid
+__global__ void __launch_bounds__(256) voxel_batch_run_kernel(VoxelBatchView v, const VoxelCloudDesc* __restrict__ desc,
+                                                               const int* __restrict__ in_off, int n_valid, const int* __restrict__ flag,
+                                                               const int* __restrict__ pos, int cell_bits, int rid_bits,
+                                                               unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
+                                                               int* __restrict__ run_first) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_valid) return;
+  if (e == n_valid - 1) run_first[pos[e]] = n_valid;
+  const int b = find_scan_off_wave(in_off, v.n_clouds, e);           // by the whole wavefront (scalar search), before the heads split off
+  if (!flag[e]) return;
+  const int k = e - in_off[b];
+  const unsigned rid = (unsigned)(pos[e] - 1);
+  const unsigned long long cell = vb_cell(v, desc[b], vb_point(v, b, k));
   const unsigned long long ck = ((unsigned long long)b << cell_bits) | (cell & ((1ull << cell_bits) - 1ull));
-  if (idx_bits > 0) keys[e] = (ck << idx_bits) | (unsigned long long)e;
-  else { keys[e] = ck; vals[e] = (unsigned)e; }
-  pts_c[e] = p;                 // the valid points, compacted: everything after the sort gathers from here
+  // rid_bits > 0: the run number rides in the low bits of the key and the (stable) radix sort only looks at the bits
+  // above it: 8 bytes per run and pass instead of 12 (key + value)
+  if (rid_bits > 0) keys[rid] = (ck << rid_bits) | (unsigned long long)rid;
+  else { keys[rid] = ck; vals[rid] = rid; }
+  run_first[rid] = e;
 }
 
 __global__ void __launch_bounds__(256) voxel_batch_flag_kernel(const unsigned long long* __restrict__ keys, int n, int idx_bits, int* __restrict__ flag) {
@@ -795,40 +822,47 @@ __global__ void __launch_bounds__(256) voxel_batch_flag_kernel(const unsigned lo
   flag[i] = (i == 0 || (keys[i] >> idx_bits) != (keys[i - 1] >> idx_bits)) ? 1 : 0;
 }
 
-// after the sort: points into key order (independent one-level gathers, coalesced writes) + the list of run heads
-__global__ void __launch_bounds__(256) voxel_batch_gather_kernel(const float4* __restrict__ pts_c, const unsigned* __restrict__ vals,
-                                                                  const unsigned long long* __restrict__ keys, int idx_bits,
-                                                                  const int* __restrict__ flag, const int* __restrict__ pos, int n,
-                                                                  float4* __restrict__ sp, int* __restrict__ head_pos) {
+// positions (in the sorted run order) of the runs that open a voxel
+__global__ void __launch_bounds__(256) voxel_batch_vhead_kernel(const int* __restrict__ flag, const int* __restrict__ pos, int n_runs,
+                                                                 int* __restrict__ head_pos) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const unsigned src = idx_bits > 0 ? (unsigned)(keys[j] & ((1ull << idx_bits) - 1ull)) : vals[j];
-  sp[j] = pts_c[src];
-  if (flag[j]) head_pos[pos[j] - 1] = j;
+  if (j < n_runs && flag[j]) head_pos[pos[j] - 1] = j;
 }
 
-// one thread per voxel: centroid of its run (contiguous in `sp`) in arrival order, f32 accumulators; the
-// voxel that opens a cloud also publishes the output boundaries of every cloud since the previous non-empty one
-__global__ void __launch_bounds__(256) voxel_batch_centroid_kernel(const float4* __restrict__ sp, const unsigned long long* __restrict__ keys,
-                                                                    const int* __restrict__ head_pos, const int* __restrict__ pos, int n,
-                                                                    int n_clouds, int cell_bits, float4* __restrict__ out,
-                                                                    int* __restrict__ out_off) {
+// one thread per voxel: its runs in sorted (= arrival) order, their points in order, f32 accumulators; the voxel that
+// opens a cloud also publishes the output boundaries of every cloud since the previous non-empty one
+__global__ void __launch_bounds__(256) voxel_batch_run_centroid_kernel(VoxelBatchView v, const int* __restrict__ in_off,
+                                                                        const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                                        const int* __restrict__ run_first, const int* __restrict__ head_pos,
+                                                                        const int* __restrict__ pos, int n_runs, int cell_bits, int rid_bits,
+                                                                        float4* __restrict__ out, int* __restrict__ out_off) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  const int m = pos[n - 1];                                    // number of voxels in the batch
+  const int m = pos[n_runs - 1];                               // number of voxels in the batch
   if (o >= m) return;
-  const int i = head_pos[o];
-  const int e = (o + 1 < m) ? head_pos[o + 1] : n;
+  const int j0 = head_pos[o];
+  const int j1 = (o + 1 < m) ? head_pos[o + 1] : n_runs;
+  const int b = (int)(keys[j0] >> (cell_bits + rid_bits));
+  const int base = in_off[b];
   float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
-  for (int j = i; j < e; j++) {
-    const float4 p = sp[j];
-    sx += p.x; sy += p.y; sz += p.z; st += p.w;
+  int total = 0;
+  for (int j = j0; j < j1; j++) {
+    const unsigned rid = rid_bits > 0 ? (unsigned)(keys[j] & ((1ull << rid_bits) - 1ull)) : vals[j];
+    const int e0 = run_first[rid], len = run_first[rid + 1] - e0, k = e0 - base;
+    total += len;
+    for (int e = 0; e < len; e += 4) {                                  // four loads in flight, added in arrival order
+      const float4 p0 = vb_point(v, b, k + e), p1 = vb_point(v, b, k + min(e + 1, len - 1)), p2 = vb_point(v, b, k + min(e + 2, len - 1)),
+                   p3 = vb_point(v, b, k + min(e + 3, len - 1));
+      sx += p0.x; sy += p0.y; sz += p0.z; st += p0.w;
+      if (e + 1 < len) { sx += p1.x; sy += p1.y; sz += p1.z; st += p1.w; }
+      if (e + 2 < len) { sx += p2.x; sy += p2.y; sz += p2.z; st += p2.w; }
+      if (e + 3 < len) { sx += p3.x; sy += p3.y; sz += p3.z; st += p3.w; }
+    }
   }
-  const float c = (float)(e - i);
+  const float c = (float)total;
   out[o] = make_float4(sx / c, sy / c, sz / c, st / c);
-  const int b = (int)(keys[i] >> cell_bits);                  // cell_bits here = cell bits + slot bits of the key
-  const int prev = i == 0 ? -1 : (int)(keys[i - 1] >> cell_bits);
+  const int prev = j0 == 0 ? -1 : (int)(keys[j0 - 1] >> (cell_bits + rid_bits));
   for (int cl = prev + 1; cl <= b; cl++) out_off[cl] = o;                 // empty clouds in between start (and end) here
-  if (e == n) for (int cl = b + 1; cl <= n_clouds; cl++) out_off[cl] = m;
+  if (j1 == n_runs) for (int cl = b + 1; cl <= v.n_clouds; cl++) out_off[cl] = m;
 }
 
 // ---- batched voxel filter, one workgroup per cloud, everything between the two reads of the points in LDS ----
