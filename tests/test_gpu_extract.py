@@ -82,6 +82,31 @@ def test_minimum_range_edge_is_the_reference_compare(gpu, oracle):
         assert np.array_equal(f["label"], fo["label"])
 
 
+def test_relative_time_wraps_wherever_they_fall(gpu, oracle):
+    """The +2 pi wrap of the relative time (msf_loam_node.cc:145-149) is found before the scatter when it falls into the
+    cloud's first 256 points and re-derived from the stored coordinates otherwise.  Full-size scans in driver order, grouped
+    by ring (a ring then starts thousands of points into the cloud), started mid-revolution (the wrap lands in the middle
+    of every ring) and reversed must all reproduce the oracle's times."""
+    pts, ring, _, _ = common.scans(1)[0]
+    n = len(pts)
+    order = np.argsort(ring, kind="stable")
+    variants = [(pts, ring), (pts[order], ring[order])]
+    for shift in (n // 3, n // 2 + 17):
+        variants.append((np.roll(pts, -shift, axis=0), np.roll(ring, -shift)))
+        variants.append((np.roll(pts[order], -shift, axis=0), np.roll(ring[order], -shift)))
+    variants.append((pts[::-1].copy(), ring[::-1].copy()))
+    wrapped = 0
+    for p, r in variants:
+        fo = oracle.extract_features(p, r)
+        _check(gpu.extract_features(p, r), fo)
+        wrapped += int(np.sum(fo["full"][:, 3] > 0.1))
+    assert wrapped > n                                                  # the wrapped times (> one scan period) really occur
+    off = np.cumsum([0] + [len(p) for p, _ in variants]).astype(np.int32)
+    res = gpu.extract_features_batch(np.concatenate([p for p, _ in variants]), np.concatenate([r for _, r in variants]), off)
+    for (p, r), f in zip(variants, res):
+        _check(f, oracle.extract_features(p, r))
+
+
 def test_hand_made_ties_and_gap_breaks(gpu, oracle):
     n = 300
     pts = np.zeros((n, 4), np.float32)
