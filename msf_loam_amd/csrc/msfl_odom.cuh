@@ -350,14 +350,24 @@ struct OdomIndex {
   int tiles;                 // workgroups per pair in the query kernel
 };
 
+struct OdomBinJob {                                      // one cloud family of the batch (less-flat / less-sharp) and where its index goes
+  const float4* pts; const uint16_t* ring; const int* off;
+  unsigned* tab; float4* sorted; OdomPairDesc* desc; int* mode;
+};
+
+// blocks [0, n_pairs) bin job a's clouds, blocks [n_pairs, 2 n_pairs) job b's (one launch for both families)
 __global__ void __launch_bounds__(1024)
-odom_bin_kernel(const float4* __restrict__ pts_all, const uint16_t* __restrict__ ring_all, const int* __restrict__ off,
-                unsigned* __restrict__ tab_all, float4* __restrict__ sorted_all, OdomPairDesc* __restrict__ desc, int* __restrict__ mode) {
+odom_bin_kernel(OdomBinJob job_a, OdomBinJob job_b, int n_pairs) {
   __shared__ unsigned s_cnt[kOdomMaxCells / 2];         // two u16 counters per word
   __shared__ int s_red[16][5];
   __shared__ unsigned s_part[16];
   __shared__ int s_box[5];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool second = (int)blockIdx.x >= n_pairs;
+  const OdomBinJob& job = second ? job_b : job_a;
+  const float4* __restrict__ pts_all = job.pts; const uint16_t* __restrict__ ring_all = job.ring; const int* __restrict__ off = job.off;
+  unsigned* __restrict__ tab_all = job.tab; float4* __restrict__ sorted_all = job.sorted;
+  OdomPairDesc* __restrict__ desc = job.desc; int* __restrict__ mode = job.mode;
+  const int b = (int)blockIdx.x - (second ? n_pairs : 0), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s0 = off[b], n = off[b + 1] - s0;
   const float4* pts = pts_all + s0;
   const uint16_t* ring = ring_all + s0;
@@ -493,16 +503,15 @@ __device__ __forceinline__ unsigned long long group_min_key(unsigned long long k
 // EDGE = false: flat queries against the less-flat cloud (:166-258); EDGE = true: sharp queries against the
 // less-sharp cloud (:81-163: second point only from rings (id, id + 2.5] above / [id - 2.5, id) below).
 template <int L, bool EDGE>
-__global__ void __launch_bounds__(kOdomBlock)
-assoc_scan2scan_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const double* __restrict__ poses,
-                            const int* __restrict__ status, double* __restrict__ rec) {
+__device__ __forceinline__ void odom_grid_query(const BatchView& bv, const OdomView& ov, const OdomIndex& ix, const double* __restrict__ poses,
+                                                const int* __restrict__ status, double* __restrict__ rec, int block) {
   // XCD-aware block -> (pair, tile) mapping.  Workgroups are dealt round-robin to the 8 XCDs (block i -> XCD i % 8)
   // and every XCD has its own L2: all `tiles` workgroups of a pair are given ids with the same residue mod 8 and
   // consecutive quotients, so one XCD reads that pair's 0.5 MB of sorted targets + column table once instead of
   // every XCD re-reading it at a different time (PMC per launch: FETCH_SIZE 1.72 -> 0.35 GB, L2 hit rate 31 -> 86 %;
   // the kernel time only moved by 4 %: it is VALU / latency bound, the misses were hidden by 8 waves/SIMD).
   const int tiles = ix.tiles;
-  const int group = blockIdx.x / (8 * tiles), within = blockIdx.x - group * (8 * tiles);
+  const int group = block / (8 * tiles), within = block - group * (8 * tiles);
   const int b = group * 8 + (within & 7);
   const int tile = within >> 3;
   if (b >= bv.n_scans) return;
@@ -624,6 +633,16 @@ assoc_scan2scan_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix, const doubl
     C = mk3((A.x + Bp.x + Cp.x) / 3, (A.y + Bp.y + Cp.y) / 3, (A.z + Bp.z + Cp.z) / 3);
   }
   out[0] = N.x; out[1] = N.y; out[2] = N.z; out[3] = dot(N, C);
+}
+
+// One launch for both query kinds: blocks [0, plane_blocks) serve the flat queries, the rest the sharp ones.  The edge
+// queries are a tenth of the work and used to run as a launch of their own behind the plane kernel's tail.
+template <int L>
+__global__ void __launch_bounds__(kOdomBlock)
+assoc_scan2scan_grid_kernel(BatchView bv, OdomView ov, OdomIndex ix_plane, OdomIndex ix_edge, int plane_blocks,
+                            const double* __restrict__ poses, const int* __restrict__ status, double* __restrict__ rec) {
+  if ((int)blockIdx.x < plane_blocks) odom_grid_query<L, false>(bv, ov, ix_plane, poses, status, rec, (int)blockIdx.x);
+  else odom_grid_query<L, true>(bv, ov, ix_edge, poses, status, rec, (int)blockIdx.x - plane_blocks);
 }
 
 }  // namespace msfl
