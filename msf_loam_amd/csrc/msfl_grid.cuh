@@ -12,8 +12,10 @@
 // single point is the point itself, re-filtering an untouched cell is the identity: InsertScan is
 // therefore "append, stable-sort everything by key (old points first), one centroid per key run"
 // — one rocPRIM radix sort + two light kernels, no per-cell containers, no pointer chasing.
-// A map point keeps the key of the run it was created from (the reference keeps a point in the cell
-// container it was pushed into and does not re-derive the cell from the centroid's coordinates).
+// A map point keeps the CELL of the run it was created from (the reference keeps a point in the cell
+// container it was pushed into and does not re-derive the cell from the centroid's coordinates); the
+// voxel part of its key is re-derived from its coordinates whenever an insert touches its cell, because
+// the reference's per-cell filter bins by coordinates (grid_rekey_touched_kernel).
 // Cost per insert is O(map + scan) (one sort over everything); merging the sorted scan into the
 // sorted map and re-filtering only the runs that received points would make it O(scan).
 // GetSurroundedCloud marks cells through a binary search over the sorted unique cell keys.
@@ -72,6 +74,38 @@ __global__ void __launch_bounds__(256) grid_point_key_kernel(const float4* __res
   }
   if (key == kGridBadKey) *bad = 1;
   keys[i] = key;
+}
+
+// cell part of the new scan's keys (sorted afterwards: the set of cells this insert touches)
+__global__ void __launch_bounds__(256) grid_cell_of_key_kernel(const unsigned long long* __restrict__ keys, int n,
+                                                                unsigned long long* __restrict__ cells) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cells[i] = keys[i] >> (3 * kGridVoxBits);
+}
+
+// The reference re-runs the voxel filter over every cell the scan touched (hybrid_grid.cc:513-520): an old centroid of
+// such a cell is binned by its COORDINATES again (an f32 centroid can round onto the next voxel's boundary and then
+// merges with that voxel's content), while it stays in the cell container it was pushed into and nothing moves in the
+// cells the scan does not touch.  So: old map points whose cell is among `touched` (sorted, duplicates allowed) get the
+// voxel part of their key re-derived from their coordinates, relative to their STORED cell; all other keys stay.
+__global__ void __launch_bounds__(256) grid_rekey_touched_kernel(const float4* __restrict__ pts, int n, GridStoreDesc d,
+                                                                  const unsigned long long* __restrict__ touched, int n_touched,
+                                                                  unsigned long long* __restrict__ keys, int* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long cell = keys[i] >> (3 * kGridVoxBits);
+  int lo = 0, hi = n_touched;                               // first entry >= cell
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (touched[mid] < cell) lo = mid + 1; else hi = mid; }
+  if (lo == n_touched || touched[lo] != cell) return;
+  const int lim_c = 1 << (kGridCellBits - 1);
+  const int ix = (int)(cell & ((1u << kGridCellBits) - 1u)) - lim_c, iy = (int)((cell >> kGridCellBits) & ((1u << kGridCellBits) - 1u)) - lim_c,
+            iz = (int)(cell >> (2 * kGridCellBits)) - lim_c;
+  const float4 p = pts[i];
+  const int rx = grid_vox_rel(p.x, ix, d), ry = grid_vox_rel(p.y, iy, d), rz = grid_vox_rel(p.z, iz, d);
+  const int lim = 1 << kGridVoxBits;
+  if (rx < 0 || rx >= lim || ry < 0 || ry >= lim || rz < 0 || rz >= lim) { *bad = 1; return; }
+  keys[i] = (cell << (3 * kGridVoxBits)) | ((unsigned long long)rz << (2 * kGridVoxBits)) | ((unsigned long long)ry << kGridVoxBits) |
+            (unsigned long long)rx;
 }
 
 // head flags of key runs (voxels) and of cell runs in the sorted key array

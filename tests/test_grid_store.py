@@ -91,6 +91,35 @@ def test_gpu_grid_matches_oracle_bit_for_bit(gpu, oracle):
 
 
 @pytest.mark.gpu
+def test_refiltering_a_touched_cell_uses_the_centroids_coordinates(gpu, oracle):
+    """HybridGrid::InsertScan re-runs the voxel filter over every cell the scan touched (hybrid_grid.cc:513-520): an old
+    centroid is binned by its COORDINATES again, and an f32 centroid can round onto the next voxel's boundary (three
+    points just below x = 1.4 with leaf 0.2 average to exactly 1.4f).  In a touched cell it must then merge with that
+    voxel's content; in a cell the scan does not touch nothing may move; and it stays in its 3 m cell container either
+    way.  Checked against the oracle (which filters each touched cell's own cloud like the reference)."""
+    from msf_loam_amd import capi
+    xs = np.array([1.3999997, 1.3999999, 1.3999999], np.float32)
+    c = np.float32(np.float32(np.float32(xs[0] + xs[1]) + xs[2]) / np.float32(3))
+    assert np.floor(xs * np.float32(5)).max() == 6 and np.floor(c * np.float32(5)) == 7      # the premise: the centroid leaves its voxel
+    def blob(x0):
+        p = np.zeros((4, 4), np.float32)
+        p[:3, 0] = xs + np.float32(x0); p[3, 0] = np.float32(1.45) + np.float32(x0)          # three points of voxel 6, one of voxel 7
+        p[:, 1] = 0.1; p[:, 2] = 0.1; p[:, 3] = [0.01, 0.02, 0.03, 0.04]
+        return p
+    first = np.concatenate([blob(0.0), blob(0.0) + np.array([0, 6.0, 0, 0], np.float32)])       # the same blob in cells (0,0,0) and (0,2,0)
+    second = np.array([[0.5, 0.3, 0.2, 0.05]], np.float32)                                       # touches cell (0,0,0) only
+    go, gg = oracle.HybridGrid(3.0, 0.2), capi.Grid(gpu, 3.0, 0.2)
+    for scan in (first, second, second + np.array([0.2, 0, 0, 0], np.float32)):
+        assert go.insert_scan(scan) == 0
+        gg.insert_scan(scan)
+        assert gg.size() == go.size()
+        assert np.array_equal(gg.dump(), go.dump())
+    d = go.dump()
+    assert np.sum(np.abs(d[:, 1] - 0.1) < 1e-3) == 1 and np.sum(np.abs(d[:, 1] - 6.1) < 1e-3) == 2   # merged where touched, apart where not
+    gg.close()
+
+
+@pytest.mark.gpu
 def test_surrounded_cloud_feeds_set_map_on_device(gpu, oracle):
     """insert -> get_surrounded (device) -> msfl_set_map (device) -> match: the mapping loop without
     the map ever leaving the GPU, against the oracle doing the same through host arrays."""
