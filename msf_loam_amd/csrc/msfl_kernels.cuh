@@ -963,7 +963,11 @@ __device__ __forceinline__ void unpack_system(const double* sys, double (&H)[6][
 
 // FinalizeIterationAndCheckIfMinimizerCanContinue + ComputeTrustRegionStep (+ HandleInvalidStep,
 // ParameterToleranceReached), lane 0 only.  Returns 1 when tr.cand holds a candidate to evaluate.
-__device__ __noinline__ int tr_propose(TrState& tr, const SolverParams& prm) {
+// `prm` BY VALUE: through a reference the (kernel-argument) structure is read with flat loads, and because the stores to
+// the LDS state in between might alias it, every use re-read its field from memory behind an `s_waitcnt vmcnt(0)` — a
+// dozen global round trips per call on a single lane (found with clock reads inside the function: the six clamps of the
+// LM diagonal alone took 7 us).
+__device__ __noinline__ int tr_propose(TrState& tr, const SolverParams prm) {
   for (;;) {
     if (tr.iteration >= prm.max_iterations) return 0;
     if (tr.step_ok && tr.gmax <= prm.gtol) return 0;
@@ -1070,7 +1074,7 @@ __device__ __noinline__ int tr_propose(TrState& tr, const SolverParams& prm) {
 
 // FunctionToleranceReached / IsStepSuccessful / HandleSuccessfulStep / HandleUnsuccessfulStep,
 // lane 0 only; `red` = {cost, g, H} evaluated at tr.cand.  Returns 1 to continue.
-__device__ __noinline__ int tr_decide(TrState& tr, const double* red, const SolverParams& prm) {
+__device__ __noinline__ int tr_decide(TrState& tr, const double* red, const SolverParams prm) {
   const double cand_cost = red[0];
   const double cost_change = tr.cost - cand_cost;
   if (fabs(cost_change) <= prm.ftol * tr.cost) return 0;
