@@ -920,13 +920,24 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
   int my_flag = 0;
   constexpr int kU = 4;                                                // chunks whose loads are in flight together
+  // A point is reached through the index list: two dependent loads.  The indices of the NEXT round are requested while
+  // this round's points are still on their way, so that a round waits for one memory round trip, not two (the points
+  // one round ahead as well: no further gain, 24 more VGPRs).
+  const int cloud_o = v.off[b];
+  auto resolve = [&](int base0, int (&dst)[kU]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const int k = min(base0 + 64 * u + lane, n - 1);                   // clamped: unconditional loads
+      dst[u] = v.idx ? v.idx[cloud_o + k] : k;
+    }
+  };
+  int src[kU];
+  resolve(k0, src);
   for (int base0 = k0; base0 < k1; base0 += 64 * kU) {
     float4 pp[kU];
 #pragma unroll
-    for (int u = 0; u < kU; u++) {
-      const int k = base0 + 64 * u + lane;
-      pp[u] = vb_point(v, b, min(k, n - 1));                             // clamped: unconditional loads, all issued before the first use
-    }
+    for (int u = 0; u < kU; u++) pp[u] = v.pts[cloud_o + src[u]];           // all issued before the first use
+    resolve(min(base0 + 64 * kU, max(k1 - 1, 0)), src);
 #pragma unroll
     for (int u = 0; u < kU; u++) {
       const int base = base0 + 64 * u;
