@@ -546,10 +546,12 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
   const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
   const bool is_edge = local < nc;
   FitOut fo; fo.ok = false; fo.C = mk3(0, 0, 0); fo.N = mk3(0, 0, 0);
-  const int p0 = in[0];
+  // all five indices at once and the five neighbours unconditionally (index 0 stands in when there is no match): behind the
+  // `p0 >= 0` test the loads came as three dependent round trips (first index, the other four, the points)
+  const int p0 = in[0], p1 = in[1], p2 = in[2], p3 = in[3], p4 = in[4];
+  const float4* mp = is_edge ? map_c : map_s;
+  const float4 nb[5] = {mp[max(p0, 0)], mp[max(p1, 0)], mp[max(p2, 0)], mp[max(p3, 0)], mp[max(p4, 0)]};
   if (p0 >= 0) {
-    const float4* mp = is_edge ? map_c : map_s;
-    const float4 nb[5] = {mp[p0], mp[in[1]], mp[in[2]], mp[in[3]], mp[in[4]]};
     fo = is_edge ? edge_fit(nb, line_ratio) : plane_fit(nb, plane_tol);
     if (DESKEW && fo.ok) {
       // C' = C - (Vi dt - G dt^2/2): the velocity block is constant (mapping_scan_matcher.cc:94)
