@@ -72,6 +72,83 @@ def test_feature_sets_obey_the_pick_rules(oracle):
     assert len(set(f["sharp"])) == len(f["sharp"])
 
 
+def _py_pick(full, ring, curv):
+    """The per-ring, per-sector pick of msf_loam_node.cc:250-345 written out as the plain loops the reference runs (sort
+    the sector by curvature, walk it downwards for corners and upwards for flats, mark +-5 neighbours across small gaps),
+    independently of the oracle's C code.  Ties in the sort are broken by index (the documented choice)."""
+    n = len(full)
+    xyz = full[:, :3].astype(np.float32)
+    label = np.zeros(n, np.uint8)
+    picked = np.zeros(n, bool)
+    sharp, less_sharp, flat, less_flat = [], [], [], []
+    def small_gap(a, b):
+        d = (xyz[a] - xyz[b]).astype(np.float32)
+        return not (np.float64(np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])) > 0.05)
+    def mark(ind, with_label):
+        picked[ind] = True
+        for l in range(1, 6):
+            if not small_gap(ind + l, ind + l - 1): break
+            picked[ind + l] = True
+            if with_label: label[ind + l] = 2
+        for l in range(-1, -6, -1):
+            if not small_gap(ind + l, ind + l + 1): break
+            picked[ind + l] = True
+            if with_label: label[ind + l] = 2
+    rings = np.unique(ring)
+    bounds = {int(r): (int(np.flatnonzero(ring == r)[0]), int(np.flatnonzero(ring == r)[-1]) + 1) for r in rings}
+    for r in range(int(ring.max()) + 1):
+        if r not in bounds: continue
+        start, end = bounds[r][0] + 5, bounds[r][1] - 6
+        if end - start < 6: continue
+        for j in range(6):
+            sp = start + (end - start) * j // 6
+            ep = start + (end - start) * (j + 1) // 6 - 1
+            idx = np.arange(sp, ep + 1)
+            order = idx[np.lexsort((idx, curv[idx]))]
+            largest = 0
+            for ind in order[::-1]:
+                if not picked[ind] and np.float64(curv[ind]) > 0.1:
+                    largest += 1
+                    if largest <= 2:
+                        label[ind] = 1; sharp.append(ind); less_sharp.append(ind)
+                    elif largest <= 20:
+                        label[ind] = 2; less_sharp.append(ind)
+                    else:
+                        break
+                    mark(ind, True)
+            smallest = 0
+            for ind in order:
+                if not picked[ind] and np.float64(curv[ind]) < 0.1:
+                    label[ind] = 3; flat.append(ind)
+                    smallest += 1
+                    if smallest >= 4: break
+                    mark(ind, False)
+            less_flat += [k for k in range(sp, ep + 1) if label[k] in (0, 3)]
+    return label, sharp, less_sharp, flat, less_flat
+
+
+def test_pick_lists_equal_a_plain_python_restatement(oracle):
+    """All four feature lists and the labels, index for index, against the loops above: a clean scan, one with holes in its
+    rings (gaps that stop the neighbour marking) and one with quantised coordinates (many equal curvatures)."""
+    w, _, _ = common.small_world(20000)
+    rng = np.random.default_rng(5)
+    for case in range(3):
+        pose = synth.random_poses(1, synth.SEED + 70 + case)[0]
+        pts, ring = synth.make_scan(w, pose, synth.SEED + 80 + case, n_az=500)
+        if case == 1:
+            keep = rng.uniform(size=len(pts)) > 0.15
+            pts, ring = pts[keep], ring[keep]
+        if case == 2:
+            pts[:, :3] = np.round(pts[:, :3] * 8) / 8
+        f = oracle.extract_features(pts, ring)
+        assert f["rc"] == 0
+        label, sharp, less_sharp, flat, less_flat = _py_pick(f["full"], f["ring"], f["curvature"])
+        assert np.array_equal(f["sharp"], sharp) and np.array_equal(f["less_sharp"], less_sharp), case
+        assert np.array_equal(f["flat"], flat) and np.array_equal(f["less_flat"], less_flat), case
+        assert np.array_equal(f["label"], label), case
+        assert len(sharp) > 50 and len(flat) > 100
+
+
 def _line_scan(n=400, ring_id=0):
     """One ring along a straight wall: tiny, equal curvatures -> exercises ties + flat picks."""
     pts = np.zeros((n, 4), np.float32)
