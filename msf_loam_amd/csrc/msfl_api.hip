@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -126,6 +127,7 @@ struct msfl_handle_s {
   MapIndex map_c, map_s;
   int grid_cap_cells = 64 * 1024 * 1024;  // hard limit of the dense cell table (MSFL_GRID_CAP_CELLS)
   int h2d_chunk_scans = 512;              // MSFL_H2D_CHUNK_SCANS: scans per PCIe chunk of a host-buffer batch (>= 2 chunks to pipeline)
+  int h2d_sub_chunks = 2;                 // MSFL_H2D_SUB_CHUNKS: pieces a chunk arrives in (its first association pass follows them)
   bool voxel_force_global = false;        // MSFL_VOXEL_GLOBAL=1: the batched voxel filter keeps the device-wide radix-sort form (A/B testing)
   bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)
 
@@ -288,10 +290,14 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
 }
 
 // one data-association pass = kNN kernel + fit kernel
-void s_launch_assoc(msfl_handle* h, const BatchView& bv, const double* d_poses, const int* d_status, bool deskew,
-                    const DeskewView& dv, int n_rec, double* full = nullptr) {
+// (records [rec_begin, rec_end) of the batch; rec_end < 0: all of them)
+void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_poses, const int* d_status, bool deskew,
+                    const DeskewView& dv, int n_rec, double* full = nullptr, int rec_begin = 0, int rec_end = -1) {
   hipStream_t st = h->stream;
   int* nn = h->nn.as<int>();
+  BatchView bv = bv_all;
+  if (rec_end >= 0) { bv.rec_begin = rec_begin; bv.n_records = rec_end; n_rec = rec_end - rec_begin; }
+  if (n_rec <= 0) return;
   const dim3 grid(div_up(n_rec, kAssocBlock)), block(kAssocBlock);
   {
     ScopedTimer timer(h, T_ASSOC);
@@ -336,9 +342,13 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv, const double* d_poses, 
 }
 
 // Core of stage C.  All pointers are device pointers except the offsets (host).
+// `n_chunks` > 1: the features of scans [chunk_b[c], chunk_b[c + 1]) are valid on the device once `chunk_ev[c]` has
+// fired (host-buffer batches: they arrive over PCIe on another stream).  The first association pass then runs chunk by
+// chunk behind the copies; everything after it sees the whole batch.
 msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner, const int* h_corner_off,
                                   const float4* d_surf, const int* h_surf_off, double* d_poses, int* d_status,
-                                  DevMatchInfo* d_info, const DeskewView* deskew) {
+                                  DevMatchInfo* d_info, const DeskewView* deskew, int n_chunks = 1, const int* chunk_b = nullptr,
+                                  hipEvent_t* chunk_ev = nullptr, const std::function<hipError_t(int)>* enqueue_chunk = nullptr) {
   hipStream_t st = h->stream;
   // offsets -> device: [corner_off (B+1) | surf_off (B+1) | rec_off (B+1)]
   std::vector<int> offs(3 * (size_t)(B + 1));
@@ -368,7 +378,15 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
   }
   const SolverParams sp = solver_params(h->prm, 0);
   for (int it = 0; it < h->prm.outer_iterations; it++) {
-    if (n_rec > 0) {
+    if (it == 0 && (n_chunks > 1 || enqueue_chunk)) {
+      for (int c = 0; c < n_chunks; c++) {
+        // the copy of chunk c is ENQUEUED here, right before the kernels that wait for it: a copy from pageable memory
+        // holds the calling thread until it is staged, and the kernels of chunk c - 1 must be in the queue by then
+        if (enqueue_chunk) HIPCHK(h, (*enqueue_chunk)(c));
+        HIPCHK(h, hipStreamWaitEvent(st, chunk_ev[c], 0));
+        s_launch_assoc(h, bv, d_poses, d_status, deskew != nullptr, dv, n_rec, nullptr, offs[2 * (B + 1) + chunk_b[c]], offs[2 * (B + 1) + chunk_b[c + 1]]);
+      }
+    } else if (n_rec > 0) {
       s_launch_assoc(h, bv, d_poses, d_status, deskew != nullptr, dv, n_rec);
     }
     {
@@ -461,6 +479,7 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
   h->stream = h->own_stream;
   if (const char* e = std::getenv("MSFL_GRID_CAP_CELLS")) { const int c = std::atoi(e); if (c >= 8 && c <= (1 << 28)) h->grid_cap_cells = c; }
   if (const char* e = std::getenv("MSFL_H2D_CHUNK_SCANS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_chunk_scans = c; }
+  if (const char* e = std::getenv("MSFL_H2D_SUB_CHUNKS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_sub_chunks = c; }
   if (const char* e = std::getenv("MSFL_ODOM_BRUTE")) h->odom_force_brute = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSFL_VOXEL_GLOBAL")) h->voxel_force_global = std::atoi(e) != 0;
   *out = h;
@@ -615,7 +634,7 @@ static msfl_status match_batch_impl(msfl_handle* h, int B, const msfl_point* cor
   std::vector<int> co(corner_off, corner_off + B + 1), so(surf_off, surf_off + B + 1);
   // Host buffers, large batch, plain branch: the features go over PCIe in chunks of >= 512 scans on a second
   // stream while the previous chunk is being registered (82 MB per 1 024 scans is as long as the compute).
-  const int n_chunks = (mem == MSFL_MEM_HOST && !deskew && B >= 2 * h->h2d_chunk_scans) ? std::min(8, B / h->h2d_chunk_scans) : 1;
+  const int n_chunks = (mem == MSFL_MEM_HOST && !deskew && B >= 2 * h->h2d_chunk_scans) ? std::min(8, B / h->h2d_chunk_scans) : 1;   // copy_ev[8] is the fork event
   if (mem == MSFL_MEM_HOST) {
     HIPCHK(h, h->in_corner.reserve(std::max<size_t>(1, (size_t)ncp) * sizeof(float4)));
     HIPCHK(h, h->in_surf.reserve(std::max<size_t>(1, (size_t)nsp) * sizeof(float4)));
@@ -677,15 +696,27 @@ static msfl_status match_batch_impl(msfl_handle* h, int B, const msfl_point* cor
     // the staging buffers may still be read by work queued earlier on the compute stream
     HIPCHK(h, hipEventRecord(h->copy_ev[8], st));
     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->copy_ev[8], 0));
-    for (int c = 0; c < n_chunks; c++) {
-      const int b0 = (int)((long long)B * c / n_chunks), b1 = (int)((long long)B * (c + 1) / n_chunks);
-      const size_t nc = (size_t)(co[b1] - co[b0]), ns = (size_t)(so[b1] - so[b0]);
-      if (nc) HIPCHK(h, hipMemcpyAsync(h->in_corner.as<float4>() + co[b0], corner + c0 + co[b0], nc * sizeof(float4), hipMemcpyHostToDevice, h->copy_stream));
-      if (ns) HIPCHK(h, hipMemcpyAsync(h->in_surf.as<float4>() + so[b0], surf + s0 + so[b0], ns * sizeof(float4), hipMemcpyHostToDevice, h->copy_stream));
-      HIPCHK(h, hipEventRecord(h->copy_ev[c], h->copy_stream));
-      HIPCHK(h, hipStreamWaitEvent(st, h->copy_ev[c], 0));
-      s = match_scan2map_device(h, b1 - b0, d_corner, co.data() + b0, d_surf, so.data() + b0, d_poses + 7 * (size_t)b0, d_status + b0,
-                                d_info ? d_info + b0 : nullptr, nullptr);
+    // Two levels.  PARTS of >= h2d_chunk_scans scans are registered one after the other, each completely (a solve over a
+    // fraction of the batch takes as long as one over all of it, so there are few parts): part p + 1 crosses PCIe while
+    // part p is being registered.  Inside a part the FIRST association pass follows its SUB-chunks as they land, so a
+    // part's kernels do not wait for all of its features either.
+    const int n_sub = std::max(1, std::min(h->h2d_sub_chunks, 8));
+    for (int p = 0; p < n_chunks; p++) {
+      const int pb0 = (int)((long long)B * p / n_chunks), pb1 = (int)((long long)B * (p + 1) / n_chunks), Bp = pb1 - pb0;
+      const int ns_p = std::max(1, std::min(n_sub, Bp / 32));
+      int sub_b[9];
+      for (int c = 0; c <= ns_p; c++) sub_b[c] = (int)((long long)Bp * c / ns_p);
+      const std::function<hipError_t(int)> enqueue_chunk = [&](int c) -> hipError_t {
+        const int b0 = pb0 + sub_b[c], b1 = pb0 + sub_b[c + 1];
+        const size_t nc = (size_t)(co[b1] - co[b0]), ns = (size_t)(so[b1] - so[b0]);
+        hipError_t e = hipSuccess;
+        if (nc) e = hipMemcpyAsync(h->in_corner.as<float4>() + co[b0], corner + c0 + co[b0], nc * sizeof(float4), hipMemcpyHostToDevice, h->copy_stream);
+        if (ns && e == hipSuccess) e = hipMemcpyAsync(h->in_surf.as<float4>() + so[b0], surf + s0 + so[b0], ns * sizeof(float4), hipMemcpyHostToDevice, h->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(h->copy_ev[c], h->copy_stream);
+        return e;
+      };
+      s = match_scan2map_device(h, Bp, d_corner, co.data() + pb0, d_surf, so.data() + pb0, d_poses + 7 * (size_t)pb0, d_status + pb0,
+                                d_info ? d_info + pb0 : nullptr, nullptr, ns_p, sub_b, h->copy_ev, &enqueue_chunk);
       if (s) return s;
     }
   }

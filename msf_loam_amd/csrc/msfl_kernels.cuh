@@ -418,7 +418,8 @@ struct BatchView {
   const float4* surf;   const int* surf_off;
   const int* rec_off;       // rec_off[b] = corner_off[b] + surf_off[b]
   int n_scans;
-  int n_records;            // rec_off[n_scans]
+  int n_records;            // rec_off[n_scans]; for the association kernels: one past the last record of this launch
+  int rec_begin = 0;        // association kernels: first record of this launch (a host-buffer batch is associated chunk by chunk as it arrives)
   int c0, s0;               // corner_off[0], surf_off[0] (host copies)
   int n_surf_total;         // surf_off[n_scans] - surf_off[0]
 };
@@ -473,7 +474,7 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
                      const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
                      const int* __restrict__ pos_c, const int* __restrict__ pos_s,
                      float max_sq_dist, DeskewView dv, int* __restrict__ nn, unsigned long long* __restrict__ n_candidates = nullptr) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = bv.rec_begin + blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bv.n_records) return;
   const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);
   int* out = nn + 5 * (size_t)g;
@@ -538,7 +539,7 @@ __global__ void __launch_bounds__(kAssocBlock, MSFL_FIT_WAVES)
 fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
                     const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
                     double* __restrict__ rec, double* __restrict__ full) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = bv.rec_begin + blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bv.n_records) return;
   const int* in = nn + 5 * (size_t)g;
   const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);

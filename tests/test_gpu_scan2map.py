@@ -103,6 +103,38 @@ def test_batch_equals_single_and_is_deterministic(gpu, oracle):
         assert np.array_equal(p, poses1[b]), "batch result must equal the single-scan call bit for bit"
 
 
+def test_host_batches_arrive_in_parts_and_pieces(gpu, oracle, monkeypatch):
+    """A host-buffer batch crosses PCIe in parts (each registered completely while the next one is copied) that arrive in
+    pieces (a part's first association pass follows them): whatever the split, every scan's result equals the unsplit
+    host call bit for bit, also with ragged scans and a scan without features."""
+    from msf_loam_amd import capi
+    _, mc, ms = common.small_world()
+    sc = common.scans(6)
+    feats = [common.features_from_oracle(oracle, p, r)[1:] for p, r, _, _ in sc]
+    corners, surfs, guesses = [], [], []
+    for i in range(40):
+        c, sf = feats[i % 6]
+        if i == 17: c, sf = c[:0], sf[:0]                    # nothing to match
+        if i % 5 == 3: c, sf = c[: len(c) // 2], sf[: len(sf) // 3]
+        corners.append(c); surfs.append(sf); guesses.append(sc[i % 6][3])
+    co = np.cumsum([0] + [len(c) for c in corners]).astype(np.int32)
+    so = np.cumsum([0] + [len(x) for x in surfs]).astype(np.int32)
+    C, S = np.concatenate(corners), np.concatenate(surfs)
+    gpu.set_map(mc, ms)
+    want, want_st, _ = gpu.match_scan2map_batch(C, co, S, so, guesses)          # 40 scans: below the default part size, one copy
+    for part, pieces in ((8, 1), (8, 3), (20, 2), (13, 8)):
+        monkeypatch.setenv("MSFL_H2D_CHUNK_SCANS", str(part))
+        monkeypatch.setenv("MSFL_H2D_SUB_CHUNKS", str(pieces))
+        h = capi.Handle(0)
+        try:
+            h.set_map(mc, ms)
+            got, got_st, _ = h.match_scan2map_batch(C, co, S, so, guesses)
+        finally:
+            h.close()
+        assert np.array_equal(got_st, want_st) and np.array_equal(got, want), (part, pieces)
+    assert np.all(want_st == 0) and np.array_equal(want[17], np.asarray(guesses[17], np.float64))    # an empty problem leaves its pose alone
+
+
 def test_edge_cases(gpu, oracle):
     from msf_loam_amd import capi
     _, mc, ms = common.small_world()
