@@ -327,8 +327,9 @@ typedef struct msfl_features {
 } msfl_features;
 
 /*   pts/ring : the sensor cloud as pcl::fromROSMsg delivers it (driver order), n points.
-   Returns MSFL_BAD_RING for ring >= 128 (CHECK at :136) and MSFL_BAD_ARG for an empty valid
-   cloud (CHECK at :186,200). */
+   Returns MSFL_BAD_RING for ring >= 128 (CHECK at :136), MSFL_BAD_ARG for an empty valid
+   cloud (CHECK at :186,200) and MSFL_CAPACITY for a ring of more than 8128 valid points (the
+   per-ring pick state is held on chip; a 128-beam sensor at 2048 columns has 2048 per ring). */
 msfl_status msfl_extract_features(msfl_handle* h,
                                   const msfl_point* pts, const uint16_t* ring, int n,
                                   const double* extrinsic_pose7,
