@@ -123,7 +123,8 @@ def test_hand_made_ties_and_gap_breaks(gpu, oracle):
 
 
 def test_big_sector_uses_global_sort_fallback(gpu, oracle):
-    """A ring with > 6*512 points forces the global-memory sort path."""
+    """A ring with > 6*512 points: its sectors do not fit the on-chip candidate array and are picked by re-reading
+    curvature and the suppression mask (there is no sort any more; the name is round 1's)."""
     rng = np.random.default_rng(11)
     n = 5000
     ang = -np.linspace(0, 2 * np.pi, n, endpoint=False)
@@ -131,6 +132,27 @@ def test_big_sector_uses_global_sort_fallback(gpu, oracle):
     pts = np.zeros((n, 4), np.float32)
     pts[:, 0] = rad * np.cos(ang); pts[:, 1] = rad * np.sin(ang); pts[:, 2] = rng.normal(0, 0.01, n)
     _check(gpu.extract_features(pts, np.zeros(n, np.uint16)), oracle.extract_features(pts, np.zeros(n, np.uint16)))
+
+
+def test_ring_capacity_is_an_error_not_a_wrong_answer(gpu, oracle):
+    """8 128 points per ring is what the pick kernel's on-chip state holds: at the limit the result is the oracle's, one
+    point more is MSFL_CAPACITY (in a batch: for that scan only)."""
+    from msf_loam_amd import capi
+    rng = np.random.default_rng(12)
+    def ring_cloud(n):
+        ang = -np.linspace(0, 2 * np.pi, n, endpoint=False)
+        rad = 12 + rng.normal(0, 0.02, n) + (np.sin(ang * 25) > 0.9) * 1.0
+        p = np.zeros((n, 4), np.float32)
+        p[:, 0] = rad * np.cos(ang); p[:, 1] = rad * np.sin(ang); p[:, 2] = rng.normal(0, 0.01, n)
+        return p, np.zeros(n, np.uint16)
+    p, r = ring_cloud(8128)
+    _check(gpu.extract_features(p, r), oracle.extract_features(p, r))
+    p2, r2 = ring_cloud(8129)
+    assert gpu.extract_features(p2, r2, allow=(capi.CAPACITY,))["rc"] == capi.CAPACITY
+    off = np.array([0, len(p), len(p) + len(p2)], np.int32)
+    res = gpu.extract_features_batch(np.concatenate([p, p2]), np.concatenate([r, r2]), off)
+    assert res[0]["rc"] == 0 and res[1]["rc"] == capi.CAPACITY
+    _check(res[0], oracle.extract_features(p, r))
 
 
 def test_extrinsic_and_error_statuses(gpu, oracle):
