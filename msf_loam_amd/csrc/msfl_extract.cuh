@@ -931,8 +931,8 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
       dst[u] = v.idx ? v.idx[cloud_o + k] : k;
     }
   };
-  int src[kU];
-  resolve(k0, src);
+  int src[kU] = {0, 0, 0, 0};
+  if (k0 < k1) resolve(k0, src);                                          // (an empty slice, or an empty cloud, reads nothing)
   for (int base0 = k0; base0 < k1; base0 += 64 * kU) {
     float4 pp[kU];
 #pragma unroll

@@ -551,7 +551,8 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
   // `p0 >= 0` test the loads came as three dependent round trips (first index, the other four, the points)
   const int p0 = in[0], p1 = in[1], p2 = in[2], p3 = in[3], p4 = in[4];
   const float4* mp = is_edge ? map_c : map_s;
-  const float4 nb[5] = {mp[max(p0, 0)], mp[max(p1, 0)], mp[max(p2, 0)], mp[max(p3, 0)], mp[max(p4, 0)]};
+  const bool have = p0 >= 0;                                  // no match: the other four slots were never written
+  const float4 nb[5] = {mp[have ? p0 : 0], mp[have ? p1 : 0], mp[have ? p2 : 0], mp[have ? p3 : 0], mp[have ? p4 : 0]};
   if (p0 >= 0) {
     fo = is_edge ? edge_fit(nb, line_ratio) : plane_fit(nb, plane_tol);
     if (DESKEW && fo.ok) {
