@@ -310,3 +310,54 @@ def test_batched_voxel_filter_lds_form_and_its_fallbacks(oracle, monkeypatch):
             check(h, base[:3] + [extra] + base[3:6], leaf)
     finally:
         h.close(); hg.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MSFL_FUZZ_SEEDS", "8"))))
+def test_randomised_voxel_clouds_both_forms(oracle, monkeypatch, seed):
+    """Differential fuzzing of the batched voxel filter: clouds made of sweeps (runs of consecutive points per voxel of
+    every length, voxels that a later sweep revisits, voxels with hundreds of points), jittered duplicates, negative and
+    offset coordinates, index lists with per-cloud counts, empty clouds in between.  The LDS form and the device-wide
+    run sort must both equal the oracle bit for bit."""
+    from msf_loam_amd import capi
+    rng = np.random.default_rng(7000 + seed)
+    leaf = float(rng.choice([0.1, 0.2, 0.4, 0.75]))
+    clouds = []
+    for _ in range(int(rng.integers(3, 9))):
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            clouds.append(np.zeros((0, 4), np.float32)); continue
+        n_sweeps = int(rng.integers(1, 12))
+        parts = []
+        centre = rng.uniform(-40, 40, 3)
+        for s_ in range(n_sweeps):
+            m = int(rng.integers(1, 2500))
+            step = rng.uniform(0.002, min(0.6, 40.0 / m))                   # long runs ... one point per voxel; extent kept below pcl's index range
+            t = np.arange(m) * step
+            d = rng.normal(size=3); d /= np.linalg.norm(d)
+            start = centre + rng.normal(0, 1.0 if kind < 3 else 0.05, 3)     # kind 3/4: the sweeps overlap heavily (revisited voxels)
+            parts.append(start[None, :] + t[:, None] * d[None, :] + rng.normal(0, 0.003, (m, 3)))
+        xyz = np.concatenate(parts)
+        if kind == 4:
+            xyz = np.concatenate([xyz, np.repeat(xyz[:50], 6, axis=0)])     # exact duplicates, far from their originals in order
+        c = np.zeros((len(xyz), 4), np.float32); c[:, :3] = xyz; c[:, 3] = rng.uniform(0, 0.1, len(xyz))
+        clouds.append(c)
+    # through an index list with per-cloud counts (what the pipeline does), slack between the clouds
+    slack = [int(rng.integers(0, 30)) for _ in clouds]
+    off = np.cumsum([0] + [len(c) + sl for c, sl in zip(clouds, slack)]).astype(np.int32)
+    full = np.zeros((off[-1], 4), np.float32); idx = np.zeros(off[-1], np.int32); cnt = np.zeros(len(clouds), np.int32)
+    for b, c in enumerate(clouds):
+        perm = rng.permutation(len(c) + slack[b])[: len(c)] if len(c) else np.zeros(0, np.int64)
+        full[off[b] + perm] = c                                              # stored scattered, listed in cloud order
+        idx[off[b]: off[b] + len(c)] = perm
+        cnt[b] = len(c)
+    h = capi.Handle(0)
+    monkeypatch.setenv("MSFL_VOXEL_GLOBAL", "1")
+    hg = capi.Handle(0)
+    try:
+        for hh in (h, hg):
+            out, out_off = hh.voxel_downsample_batch(full, off, leaf, idx=idx, count=cnt)
+            for b, c in enumerate(clouds):
+                ref = oracle.voxel_grid(c, leaf) if len(c) else np.zeros((0, 4), np.float32)
+                assert np.array_equal(out[out_off[b]:out_off[b + 1]], ref), (seed, leaf, b, len(c))
+    finally:
+        h.close(); hg.close()
