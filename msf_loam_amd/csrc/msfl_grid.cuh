@@ -125,8 +125,10 @@ __global__ void __launch_bounds__(256)
 grid_centroid_kernel(const float4* __restrict__ pts, const int* __restrict__ order, const unsigned long long* __restrict__ keys,
                      const int* __restrict__ vox_head, const int* __restrict__ vox_pos, const int* __restrict__ cell_head,
                      const int* __restrict__ cell_pos, int n, float4* __restrict__ out_pts, unsigned long long* __restrict__ out_keys,
-                     unsigned long long* __restrict__ cell_keys, int* __restrict__ cell_start) {
+                     unsigned long long* __restrict__ cell_keys, int* __restrict__ cell_start,
+                     const int* __restrict__ bad, int* __restrict__ result) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == n - 1) { result[0] = vox_pos[i]; result[1] = cell_pos[i]; result[2] = *bad; }   // {points, cells, out-of-range flag}: one read-back
   if (i >= n || !vox_head[i]) return;
   const unsigned long long k = keys[i];
   float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
