@@ -129,6 +129,7 @@ struct msfl_handle_s {
   int h2d_chunk_scans = 512;              // MSFL_H2D_CHUNK_SCANS: scans per PCIe chunk of a host-buffer batch (>= 2 chunks to pipeline)
   int h2d_sub_chunks = 2;                 // MSFL_H2D_SUB_CHUNKS: pieces a chunk arrives in (its first association pass follows them)
   bool voxel_force_global = false;        // MSFL_VOXEL_GLOBAL=1: the batched voxel filter keeps the device-wide radix-sort form (A/B testing)
+  long long odom_wave_max_targets = -1;   // MSFL_ODOM_WAVE_MAX_TARGETS: previous-scan points up to which a small batch takes the one-wavefront-per-query kernel (default 4096 per pair)
   bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)
 
   // scratch
@@ -481,6 +482,7 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
   if (const char* e = std::getenv("MSFL_H2D_CHUNK_SCANS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_chunk_scans = c; }
   if (const char* e = std::getenv("MSFL_H2D_SUB_CHUNKS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_sub_chunks = c; }
   if (const char* e = std::getenv("MSFL_ODOM_BRUTE")) h->odom_force_brute = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MSFL_ODOM_WAVE_MAX_TARGETS")) h->odom_wave_max_targets = std::atoll(e);
   if (const char* e = std::getenv("MSFL_VOXEL_GLOBAL")) h->voxel_force_global = std::atoi(e) != 0;
   *out = h;
   return MSFL_OK;

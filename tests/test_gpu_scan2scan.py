@@ -89,9 +89,10 @@ def test_unsorted_rings_follow_reference_break_semantics(gpu, oracle):
     assert dt < TIGHT and dr < TIGHT
 
 
-def test_tiled_throughput_kernel_equals_wave_latency_kernel(gpu, oracle):
-    """Small calls use one wavefront per query, large batches the LDS-tiled kernel (256 queries per
-    workgroup).  A 42-pair batch (tiled) must reproduce the single-pair calls (wave) bit for bit."""
+def test_tiled_throughput_kernel_equals_wave_latency_kernel(gpu, oracle, monkeypatch):
+    """Small calls against a small previous cloud use one wavefront per query (a single pair with a full-size cloud goes
+    through the column grid like a batch), large batches the LDS-tiled kernel / the column grid.  A 42-pair batch must
+    reproduce the single-pair calls bit for bit, whichever kernel those take."""
     ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
     base = [_clouds(*_pair(oracle, i)) for i in range(3)]
     pairs = [base[i % 3] for i in range(42)]
@@ -110,6 +111,14 @@ def test_tiled_throughput_kernel_equals_wave_latency_kernel(gpu, oracle):
     for b in (0, 1, 2, 20, 41):
         s, p, _ = gpu.match_scan2scan(*pairs[b], guesses[b])
         assert s == 0 and np.array_equal(p, poses[b]), b
+    monkeypatch.setenv("MSFL_ODOM_WAVE_MAX_TARGETS", "1000000000")       # single pairs on the wave kernel whatever their size
+    hw = capi.Handle(0)
+    try:
+        for b in (0, 1, 2, 20, 41):
+            s, p, _ = hw.match_scan2scan(*pairs[b], guesses[b])
+            assert s == 0 and np.array_equal(p, poses[b]), b
+    finally:
+        hw.close()
     rc, pose_o, _ = oracle.match_scan2scan(*pairs[7], guesses[7])
     assert max(synth.pose_error(poses[7], pose_o)) < TIGHT
 
@@ -197,10 +206,11 @@ def test_empty_and_nonfinite_clouds(gpu, oracle):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MSFL_FUZZ_SEEDS", "6"))))
-def test_randomised_pairs_three_paths_agree(gpu, oracle, seed):
+def test_randomised_pairs_three_paths_agree(gpu, oracle, seed, monkeypatch):
     """Differential fuzzing of stage B: previous-scan clouds thinned per ring, rings removed, a block of the
-    cloud moved out of order, large initial offsets.  Single-pair call (wave kernel), 45-pair batch (tiled
-    edges + column-grid planes or the brute-force fallback) and the oracle must agree."""
+    cloud moved out of order, large initial offsets.  Single-pair call (column grid, or the wave kernel for a small
+    previous cloud), the same call forced onto the wave kernel, 45-pair batch (tiled edges + column-grid planes or the
+    brute-force fallback) and the oracle must agree."""
     rng = np.random.default_rng(4000 + seed)
     ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
     base = list(_clouds(*_pair(oracle, seed % 4)))
@@ -225,6 +235,13 @@ def test_randomised_pairs_three_paths_agree(gpu, oracle, seed):
     assert s == rc
     assert list(info_g.n_edge) == list(info_o.n_edge) and list(info_g.n_plane) == list(info_o.n_plane)
     assert max(synth.pose_error(pose_g, pose_o)) < TIGHT
+    monkeypatch.setenv("MSFL_ODOM_WAVE_MAX_TARGETS", "1000000000")
+    hw = capi.Handle(0)
+    try:
+        sw, pose_w, _ = hw.match_scan2scan(*c, guess)
+    finally:
+        hw.close()
+    assert sw == s and np.array_equal(pose_w, pose_g)
     pairs = [c] * 45
     guesses = np.stack([guess] * 45)
     poses, status, _ = gpu.match_scan2scan_batch(_batch_sets(pairs), guesses)
