@@ -377,6 +377,18 @@ msfl_status msfl_voxel_downsample_batch(msfl_handle* h, int n_clouds,
                                         const int* count, float leaf,
                                         msfl_point* out, int* out_off, msfl_mem mem);
 
+/* Two index lists over the same clouds in one call: the corner (0.2 m) and surf (0.4 m) filters that
+   the mapping thread runs back to back on every scan (laser_mapping.cc:264-270).  Same results as two
+   msfl_voxel_downsample_batch calls (list a, then list b; every argument as there, idx_* and count_*
+   required); with device memory both filters are enqueued before the one synchronisation that
+   delivers both boundary tables, so the small corner kernels do not wait for a host round trip. */
+msfl_status msfl_voxel_downsample_batch_pair(msfl_handle* h, int n_clouds,
+                                             const msfl_point* pts, const int* off,
+                                             const int* idx_a, const int* count_a, float leaf_a,
+                                             msfl_point* out_a, int* out_off_a,
+                                             const int* idx_b, const int* count_b, float leaf_b,
+                                             msfl_point* out_b, int* out_off_b, msfl_mem mem);
+
 /* TransformPointCloud (laser_mapping.cc:24-31 -> TransformPoint, rigid_transform.h:131-137): every
    point goes f32 -> f64 -> q*p + t -> f32, t (relative time) is carried over.  pose7 is always a
    host array; in == out is allowed. */

@@ -22,7 +22,8 @@ EXPORTED = [
     "msfl_match_scan2map_deskew_batch",
     "msfl_associate_scan2map", "msfl_solve_records",
     "msfl_match_scan2scan", "msfl_match_scan2scan_batch", "msfl_extract_features",
-    "msfl_extract_features_batch", "msfl_voxel_downsample", "msfl_voxel_downsample_batch", "msfl_transform_cloud",
+    "msfl_extract_features_batch", "msfl_voxel_downsample", "msfl_voxel_downsample_batch", "msfl_voxel_downsample_batch_pair",
+    "msfl_transform_cloud",
     "msfl_delta_qp", "msfl_deskew_cloud", "msfl_undistort_cloud",
     "msfl_grid_create", "msfl_grid_destroy", "msfl_grid_insert_scan", "msfl_grid_get_surrounded", "msfl_grid_size", "msfl_grid_dump",
 ]

@@ -141,6 +141,7 @@ struct msfl_handle_s {
   DevBuf ex[16];
   DevBuf od[20];
   DevBuf vb[14];  // batched voxel filter
+  DevBuf vb2[6];  // second scratch set of the pair form: staging, run sums, counts/flags/offsets, offsets
   DevBuf pp[5];   // per-point passes: pre-integration samples, staged points, dq, dp, flag
 
   PinRing pin;
@@ -522,6 +523,7 @@ void msfl_destroy(msfl_handle* h) {
   for (auto& b : h->od) b.release();
   for (auto& b : h->pp) b.release();
   for (auto& b : h->vb) b.release();
+  for (auto& b : h->vb2) b.release();
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }

@@ -10,7 +10,7 @@ int main(void) {
   const void* fns[] = {(const void*)msfl_create, (const void*)msfl_destroy, (const void*)msfl_set_map, (const void*)msfl_match_scan2map,
                        (const void*)msfl_match_scan2map_batch, (const void*)msfl_match_scan2map_deskew, (const void*)msfl_match_scan2map_deskew_batch,
                        (const void*)msfl_match_scan2scan, (const void*)msfl_match_scan2scan_batch, (const void*)msfl_extract_features,
-                       (const void*)msfl_extract_features_batch, (const void*)msfl_voxel_downsample, (const void*)msfl_voxel_downsample_batch,
+                       (const void*)msfl_extract_features_batch, (const void*)msfl_voxel_downsample, (const void*)msfl_voxel_downsample_batch, (const void*)msfl_voxel_downsample_batch_pair,
                        (const void*)msfl_transform_cloud, (const void*)msfl_delta_qp, (const void*)msfl_deskew_cloud, (const void*)msfl_undistort_cloud,
                        (const void*)msfl_grid_create, (const void*)msfl_grid_insert_scan, (const void*)msfl_grid_get_surrounded};
   size_t n = sizeof(fns) / sizeof(fns[0]), i, ok = 0;

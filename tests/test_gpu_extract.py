@@ -361,3 +361,55 @@ def test_randomised_voxel_clouds_both_forms(oracle, monkeypatch, seed):
                 assert np.array_equal(out[out_off[b]:out_off[b + 1]], ref), (seed, leaf, b, len(c))
     finally:
         h.close(); hg.close()
+
+
+def test_voxel_pair_call_equals_the_two_batch_calls(gpu, oracle):
+    """msfl_voxel_downsample_batch_pair on device memory (both filters enqueued before one synchronisation) against the two
+    plain batch calls: feature lists of real scans with per-cloud counts, an empty list in the middle; then a batch with a
+    cloud above the LDS form's point limit in list b only (that list alone is redone by the device-wide form)."""
+    import ctypes as C
+    import torch
+    from msf_loam_amd import capi
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(31)
+    sc = common.scans(5)
+    feats = [oracle.extract_features(p, r) for p, r, _, _ in sc]
+    def run(feats, extra_b=None):
+        sizes = [len(f["full"]) for f in feats]
+        if extra_b is not None: sizes[2] = max(sizes[2], len(extra_b))
+        off = np.cumsum([0] + sizes).astype(np.int32)
+        n = int(off[-1])
+        full = np.zeros((n, 4), np.float32); ia = np.zeros(n, np.int32); ib = np.zeros(n, np.int32)
+        ca = np.zeros(len(feats), np.int32); cb = np.zeros(len(feats), np.int32)
+        for b, f in enumerate(feats):
+            full[off[b]:off[b] + len(f["full"])] = f["full"]
+            la, lb = f["less_sharp"], f["less_flat"]
+            if b == 1: la = la[:0]
+            if b == 2 and extra_b is not None:
+                full[off[b]:off[b] + len(extra_b)] = extra_b; lb = np.arange(len(extra_b), dtype=np.int32)
+            ia[off[b]:off[b] + len(la)] = la; ca[b] = len(la)
+            ib[off[b]:off[b] + len(lb)] = lb; cb[b] = len(lb)
+        t = lambda a: torch.from_numpy(a).to(dev)
+        d_full, d_ia, d_ib, d_ca, d_cb = t(full), t(ia), t(ib), t(ca), t(cb)
+        outs = [torch.zeros((n, 4), dtype=torch.float32, device=dev) for _ in range(4)]
+        oo = [np.zeros(len(feats) + 1, np.int32) for _ in range(4)]
+        vp = C.c_void_p
+        B = len(feats)
+        s = gpu.lib.msfl_voxel_downsample_batch_pair(gpu.h, C.c_int(B), vp(d_full.data_ptr()), off.ctypes.data_as(vp),
+                                                     vp(d_ia.data_ptr()), vp(d_ca.data_ptr()), C.c_float(0.2), vp(outs[0].data_ptr()), oo[0].ctypes.data_as(vp),
+                                                     vp(d_ib.data_ptr()), vp(d_cb.data_ptr()), C.c_float(0.4), vp(outs[1].data_ptr()), oo[1].ctypes.data_as(vp),
+                                                     C.c_int(capi.MEM_DEVICE))
+        assert s == 0, s
+        for k, (di, dc, leaf) in enumerate(((d_ia, d_ca, 0.2), (d_ib, d_cb, 0.4))):
+            s = gpu.lib.msfl_voxel_downsample_batch(gpu.h, C.c_int(B), vp(d_full.data_ptr()), vp(di.data_ptr()), off.ctypes.data_as(vp),
+                                                    vp(dc.data_ptr()), C.c_float(leaf), vp(outs[2 + k].data_ptr()), oo[2 + k].ctypes.data_as(vp),
+                                                    C.c_int(capi.MEM_DEVICE))
+            assert s == 0, s
+            assert np.array_equal(oo[k], oo[2 + k])
+            m = int(oo[k][-1])
+            assert m > 0 and np.array_equal(outs[k][:m].cpu().numpy(), outs[2 + k][:m].cpu().numpy())
+        return oo
+    oo = run(feats)
+    assert oo[0][2] == oo[0][1]                                            # the empty list
+    big = np.zeros((70000, 4), np.float32); big[:, :3] = rng.uniform(-25, 25, (70000, 3))
+    run(feats, extra_b=big)
