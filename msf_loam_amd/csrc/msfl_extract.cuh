@@ -1146,13 +1146,19 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   // the later runs of voxel r added point by point to (sx, sy, sz, st); returns the voxel's point count
   auto later_runs = [&](int j0, int j1, float& sx, float& sy, float& sz, float& st) {
     int total = 0;
+    auto resolve4 = [&](int k, int e, int len, int (&src)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const int kk = k + min(e + i, len - 1); src[i] = v.idx ? v.idx[cloud_o + kk] : kk; }
+    };
     for (int j = j0 + 1; j < j1; j++) {
       const unsigned long long rec = s_run[s_ord[cur][j]];
       const int k = (int)((rec >> 6) & 0xffffu), len = (int)(rec & 0x3fu) + 1;
       total += len;
-      for (int e = 0; e < len; e += 4) {                                // four loads in flight, added in arrival order
-        const float4 p0 = vb_point(v, b, k + e), p1 = vb_point(v, b, k + min(e + 1, len - 1)), p2 = vb_point(v, b, k + min(e + 2, len - 1)),
-                     p3 = vb_point(v, b, k + min(e + 3, len - 1));
+      int src[4];
+      resolve4(k, 0, len, src);
+      for (int e = 0; e < len; e += 4) {                                // four loads in flight (their indices a round ahead), added in arrival order
+        const float4 p0 = v.pts[cloud_o + src[0]], p1 = v.pts[cloud_o + src[1]], p2 = v.pts[cloud_o + src[2]], p3 = v.pts[cloud_o + src[3]];
+        if (e + 4 < len) resolve4(k, e + 4, len, src);
         sx += p0.x; sy += p0.y; sz += p0.z; st += p0.w;               // CentroidPoint accumulators (f32), arrival order
         if (e + 1 < len) { sx += p1.x; sy += p1.y; sz += p1.z; st += p1.w; }
         if (e + 2 < len) { sx += p2.x; sy += p2.y; sz += p2.z; st += p2.w; }
