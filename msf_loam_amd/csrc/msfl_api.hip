@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -33,9 +34,9 @@ struct DevBuf {
   size_t cap = 0;
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    size_t want = std::max(bytes, cap + cap / 2);          // geometric growth: a buffer that grows a little per call
+    want = (want + 255) & ~size_t(255);                    // (the map store's) is not reallocated on every call
     if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
-    size_t want = std::max(bytes, cap + cap / 2);
-    want = (want + 255) & ~size_t(255);
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
     return e;
@@ -58,10 +59,10 @@ struct PinRing {
     hipError_t e;
     if (s.pending) { e = hipEventSynchronize(s.ev); if (e != hipSuccess) return e; s.pending = false; }
     if (bytes > s.cap) {
+      // generous floor and geometric growth: growing a slot costs a hipHostFree + hipHostMalloc (tens of milliseconds, and
+      // it happened once per slot as soon as a (B+1)-int offset table of a 1 024-scan batch met a 4 KB slot)
+      const size_t want = (std::max<size_t>(std::max(bytes, s.cap + s.cap / 2), 256 * 1024) + 4095) & ~size_t(4095);
       if (s.p) { e = hipHostFree(s.p); if (e != hipSuccess) return e; s.p = nullptr; s.cap = 0; }
-      // generous floor: growing a slot later costs a hipHostFree + hipHostMalloc (tens of milliseconds, and it
-      // happened once per slot as soon as a (B+1)-int offset table of a 1 024-scan batch met a 4 KB slot)
-      size_t want = (std::max<size_t>(bytes, 256 * 1024) + 4095) & ~size_t(4095);
       e = hipHostMalloc(&s.p, want, hipHostMallocDefault); if (e != hipSuccess) return e;
       s.cap = want;
     }
@@ -88,8 +89,8 @@ struct PinBuf {
   void* p = nullptr; size_t cap = 0;
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    const size_t want = (std::max<size_t>(std::max(bytes, cap + cap / 2), 4096) + 4095) & ~size_t(4095);
     if (p) { hipError_t e = hipHostFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
-    const size_t want = (std::max<size_t>(bytes, 4096) + 4095) & ~size_t(4095);
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (e == hipSuccess) cap = want;
     return e;

@@ -350,6 +350,11 @@ struct OdomIndex {
   int tiles;                 // workgroups per pair in the query kernel
 };
 
+#ifndef MSFL_ODOM_BIN_KEEP
+#define MSFL_ODOM_BIN_KEEP 20
+#endif
+constexpr int kOdomBinKeep = MSFL_ODOM_BIN_KEEP;        // points per thread the binning kernel keeps in registers (x 1 024 threads)
+
 struct OdomBinJob {                                      // one cloud family of the batch (less-flat / less-sharp) and where its index goes
   const float4* pts; const uint16_t* ring; const int* off;
   unsigned* tab; float4* sorted; OdomPairDesc* desc; int* mode;
@@ -373,15 +378,37 @@ odom_bin_kernel(OdomBinJob job_a, OdomBinJob job_b, int n_pairs) {
   const uint16_t* ring = ring_all + s0;
   unsigned* tab = tab_all + (size_t)b * kOdomTabStride;
   // ---- bounding box in columns + the conditions the grid relies on ----
+  // The first kOdomBinKeep x 1024 points stay in registers for the two later passes (xyz + the packed ring / index word the
+  // sorted copy carries): their loads are all requested before the first is used, and the histogram and scatter passes
+  // do not go back to memory for them.  Longer clouds run the rest through the streaming loops.
   int lox = INT32_MAX, loy = INT32_MAX, hix = INT32_MIN, hiy = INT32_MIN, bad = n > 65535 ? 1 : 0;
-  for (int i = tid; i < n; i += 1024) {
-    const float4 p = pts[i];
-    const int r = ring[i];
-    if (!(fabsf(p.x) < (float)kOdomRange && fabsf(p.y) < (float)kOdomRange && fabsf(p.z) < 1e30f) || r >= 256) { bad = 1; continue; }
-    if (i > 0 && ring[i - 1] > r) bad = 1;
-    const int cx = (int)floorf(p.x), cy = (int)floorf(p.y);
+  float kx[kOdomBinKeep], ky[kOdomBinKeep], kz[kOdomBinKeep];
+  unsigned kring[(kOdomBinKeep + 3) / 4];                        // four 8-bit ring ids per word
+  auto check = [&](float x, float y, float z, int r, int rprev, int i) {
+    if (!(fabsf(x) < (float)kOdomRange && fabsf(y) < (float)kOdomRange && fabsf(z) < 1e30f) || r >= 256) { bad = 1; return; }
+    if (i > 0 && rprev > r) bad = 1;
+    const int cx = (int)floorf(x), cy = (int)floorf(y);
     lox = min(lox, cx); hix = max(hix, cx); loy = min(loy, cy); hiy = max(hiy, cy);
+  };
+#pragma unroll
+  for (int k = 0; k < (kOdomBinKeep + 3) / 4; k++) kring[k] = 0;
+  if (n > 0) {
+#pragma unroll
+    for (int k = 0; k < kOdomBinKeep; k++) {
+      if (1024 * k >= n) break;                                   // uniform
+      const int i = tid + 1024 * k, ic = min(i, n - 1);
+      const float4 p = pts[ic];
+      const int r = ring[ic], rprev = ring[max(ic - 1, 0)];
+      kx[k] = p.x; ky[k] = p.y; kz[k] = p.z;
+      kring[k / 4] |= ((unsigned)r & 0xffu) << (8 * (k & 3));
+      if (i < n) check(p.x, p.y, p.z, r, rprev, i);
+    }
   }
+  auto kept = [&](int k) {                                        // the sorted copy's form of slot k: xyz + (ring << 24 | index)
+    return make_float4(kx[k], ky[k], kz[k],
+                       __int_as_float((int)(((kring[k / 4] >> (8 * (k & 3))) & 0xffu) << 24 | (unsigned)(tid + 1024 * k))));
+  };
+  for (int i = tid + 1024 * kOdomBinKeep; i < n; i += 1024) { const float4 p = pts[i]; check(p.x, p.y, p.z, ring[i], ring[i - 1], i); }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     lox = min(lox, __shfl_xor(lox, o)); loy = min(loy, __shfl_xor(loy, o));
@@ -406,10 +433,34 @@ odom_bin_kernel(OdomBinJob job_a, OdomBinJob job_b, int n_pairs) {
   // ---- histogram ----
   for (int k = tid; k < (cells + 1) / 2; k += 1024) s_cnt[k] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += 1024) {
-    const float4 p = pts[i];
-    const int c = ((int)floorf(p.y) - oy) * W + ((int)floorf(p.x) - ox);
-    atomicAdd(&s_cnt[c >> 1], 1u << (16 * (c & 1)));
+  // Consecutive points of a ring sweep mostly fall into the same column (a column is 1 m, neighbouring returns are centimetres
+  // apart), so 64 single-point atomics of a wavefront would serialise on two or three counter words.  Lanes holding a run
+  // of equal columns are found with one ballot; the run's first lane adds (here) or claims (scatter) the whole run.
+  const int wave_i0 = tid & ~63;
+  auto run_of = [&](bool valid, int c, int& head_lane, int& len) {
+    const int cc = valid ? c : -1 - lane;                         // lanes past the end: runs of their own, never used
+    const int cprev = __shfl_up(cc, 1);
+    const bool head = lane == 0 || cc != cprev;
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long upto = (2ull << lane) - 1ull;        // lanes 0..lane (lane 63: all ones)
+    head_lane = 63 - __clzll((long long)(hm & upto));
+    const unsigned long long above = hm & ~upto;
+    len = (above ? __ffsll((long long)above) - 1 : 64) - head_lane;
+    return head;
+  };
+  auto count = [&](bool valid, int c) {
+    int hl, len;
+    if (run_of(valid, c, hl, len) && valid) atomicAdd(&s_cnt[c >> 1], (unsigned)len << (16 * (c & 1)));
+  };
+#pragma unroll
+  for (int k = 0; k < kOdomBinKeep; k++) {
+    if (wave_i0 + 1024 * k >= n) break;                           // uniform in the wavefront
+    count(tid + 1024 * k < n, ((int)floorf(ky[k]) - oy) * W + ((int)floorf(kx[k]) - ox));
+  }
+  for (int i0 = wave_i0 + 1024 * kOdomBinKeep; i0 < n; i0 += 1024) {
+    const int i = i0 + lane;
+    const float4 p = pts[min(i, n - 1)];
+    count(i < n, ((int)floorf(p.y) - oy) * W + ((int)floorf(p.x) - ox));
   }
   __syncthreads();
   // ---- exclusive scan: every thread owns an even-sized run of columns ----
@@ -430,14 +481,27 @@ odom_bin_kernel(OdomBinJob job_a, OdomBinJob job_b, int n_pairs) {
   __syncthreads();
   // ---- scatter: a column's points land in its run in arbitrary order (the minima are order-free) ----
   float4* sorted = sorted_all + s0;
-  for (int i = tid; i < n; i += 1024) {
-    float4 p = pts[i];
+  auto place = [&](bool valid, const float4 p) {
     const int c = ((int)floorf(p.y) - oy) * W + ((int)floorf(p.x) - ox);
+    int hl, len;
+    const bool head = run_of(valid, c, hl, len);
     const unsigned sh = 16 * (c & 1);
-    const unsigned old = atomicSub(&s_cnt[c >> 1], 1u << sh);
-    const unsigned k = ((old >> sh) & 0xffffu) - 1u;
-    p.w = __int_as_float((int)(((unsigned)ring[i] & 0xffu) << 24 | (unsigned)i));
-    sorted[tab[c] + k] = p;
+    unsigned old = 0;
+    if (head && valid) old = atomicSub(&s_cnt[c >> 1], (unsigned)len << sh);
+    old = __shfl(old, hl);                                        // the run's first lane claimed slots [left - len, left)
+    const unsigned k = ((old >> sh) & 0xffffu) - 1u - (unsigned)(lane - hl);
+    if (valid) sorted[tab[c] + k] = p;
+  };
+#pragma unroll
+  for (int k = 0; k < kOdomBinKeep; k++) {
+    if (wave_i0 + 1024 * k >= n) break;
+    place(tid + 1024 * k < n, kept(k));
+  }
+  for (int i0 = wave_i0 + 1024 * kOdomBinKeep; i0 < n; i0 += 1024) {
+    const int i = i0 + lane, ic = min(i, n - 1);
+    float4 p = pts[ic];
+    p.w = __int_as_float((int)(((unsigned)ring[ic] & 0xffu) << 24 | (unsigned)i));
+    place(i < n, p);
   }
 }
 
