@@ -176,6 +176,42 @@ def test_column_grid_planes_equal_brute_force(gpu, oracle, monkeypatch):
     assert np.array_equal(status, status2) and np.array_equal(poses, poses2)
 
 
+def test_binning_a_cloud_longer_than_its_register_resident_part(gpu, oracle, monkeypatch):
+    """The column-grid binning kernel keeps the first 20 x 1 024 points of a previous-scan cloud in registers between
+    its passes and streams the rest.  A less-flat cloud of ~2.2x that length (ring-monotone, < 65 536 points: still
+    the grid path) must give the brute-force kernel's poses bit for bit, and the oracle's within the parity bound."""
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    rng = np.random.default_rng(23)
+    pairs = []
+    for i in range(2):
+        c = [np.copy(a) for a in _clouds(*_pair(oracle, i))]
+        pts = [c[2]]
+        for _ in range(2):                                        # two jittered copies: a denser previous scan
+            q = np.copy(c[2]); q[:, :3] += rng.normal(0, 0.03, (len(q), 3)).astype(np.float32); pts.append(q)
+        cat, ring = np.concatenate(pts)[: 45000], np.concatenate([c[3]] * 3)[: 45000]
+        order = np.argsort(ring, kind="stable")
+        c[2], c[3] = np.ascontiguousarray(cat[order]), np.ascontiguousarray(ring[order])
+        assert 2 * 20 * 1024 < len(c[2]) < 65536
+        pairs.append(c)
+    batch = [pairs[i % 2] for i in range(40)]                     # a batch large enough for the throughput path
+    guesses = np.stack([ident] * 40)
+    guesses[:, 0] = np.linspace(-0.4, 0.4, 40)
+    sets = _batch_sets(batch)
+    poses, status, info = gpu.match_scan2scan_batch(sets, guesses, want_info=True)
+    assert np.all(status == 0)
+    monkeypatch.setenv("MSFL_ODOM_BRUTE", "1")
+    h2 = capi.Handle(0)
+    try:
+        poses2, status2, _ = h2.match_scan2scan_batch(sets, guesses)
+    finally:
+        h2.close()
+    assert np.array_equal(status, status2) and np.array_equal(poses, poses2)
+    for b in (0, 1, 39):
+        rc, pose_o, info_o = oracle.match_scan2scan(*batch[b], guesses[b])
+        assert rc == 0 and list(info[b].n_plane) == list(info_o.n_plane)
+        assert max(synth.pose_error(poses[b], pose_o)) < TIGHT
+
+
 def test_empty_and_nonfinite_clouds(gpu, oracle):
     """Empty previous-scan clouds (the reference never guards them, odometry_scan_matcher.cc:57-61) give
     'too few correspondences'; NaN points must not poison neighbours, on any of the three kernels."""
