@@ -4,6 +4,8 @@ Tolerances: kNN / accept decisions are integer work -> identical accept sets; fi
 poses are f64 -> 1e-9 on records, 1e-4 m / 1e-4 rad on poses is the north-star bar; we assert the
 much tighter 1e-7 that the implementation actually reaches.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -82,6 +84,44 @@ def test_match_scan2map_pose_parity(gpu, oracle):
         assert list(info_g.lm_iterations) == list(info_o.lm_iterations)
         # and the registration actually registers: closer to truth than the guess
         assert synth.pose_error(pose_g, truth)[0] < 0.25 * synth.pose_error(guess, truth)[0] + 0.01
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MSFL_FUZZ_SEEDS", "6"))))
+def test_randomised_maps_and_guesses_follow_the_oracle(gpu, oracle, seed):
+    """Differential fuzzing of the hot path: the local map thinned at random and with a box cut out of it (sparse
+    neighbourhoods, features with fewer than five map points inside the 1 m gate), feature lists thinned, the guess up
+    to ~1 m / 3 degrees off (few accepted correspondences, the trust region shrinking, solves that stop early).  Status,
+    accepted-correspondence counts and LM iteration counts of both outer iterations must equal the oracle's, the pose
+    must agree to 1e-7, and the same scan in a batch must give the single call's bits."""
+    rng = np.random.default_rng(7000 + seed)
+    _, mc, ms = common.small_world()
+    keep_c = rng.uniform(size=len(mc)) < rng.uniform(0.3, 1.0)
+    keep_s = rng.uniform(size=len(ms)) < rng.uniform(0.15, 1.0)
+    lo = rng.uniform(-15, 5, 3); hi = lo + rng.uniform(2, 12, 3)
+    keep_s &= ~np.all((ms[:, :3] > lo) & (ms[:, :3] < hi), axis=1)
+    mc2, ms2 = np.ascontiguousarray(mc[keep_c]), np.ascontiguousarray(ms[keep_s])
+    pts, ring, truth, guess = common.scans(4)[seed % 4]
+    _, corner, surf = common.features_from_oracle(oracle, pts, ring)
+    corner = np.ascontiguousarray(corner[rng.uniform(size=len(corner)) < rng.uniform(0.3, 1.0)])
+    surf = np.ascontiguousarray(surf[rng.uniform(size=len(surf)) < rng.uniform(0.2, 1.0)])
+    g = np.array(truth, np.float64)
+    g[:3] += rng.normal(0, rng.choice([0.05, 0.3, 0.6]), 3)
+    axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+    ang = rng.normal(0, rng.choice([0.005, 0.03]))
+    dq = np.concatenate([np.sin(ang / 2) * axis, [np.cos(ang / 2)]])
+    x, y, z, w = g[3:]; a, b, c, d = dq                                  # g.q * dq (xyzw)
+    g[3:] = [w * a + x * d + y * c - z * b, w * b - x * c + y * d + z * a, w * c + x * b - y * a + z * d, w * d - x * a - y * b - z * c]
+    gpu.set_map(mc2, ms2)
+    rc, pose_o, info_o = oracle.match_scan2map(mc2, ms2, corner, surf, g)
+    s, pose_g, info_g = gpu.match_scan2map(corner, surf, g)
+    assert s == rc
+    assert list(info_g.n_edge) == list(info_o.n_edge) and list(info_g.n_plane) == list(info_o.n_plane)
+    assert list(info_g.lm_iterations) == list(info_o.lm_iterations)
+    dt, dr = synth.pose_error(pose_g, pose_o)
+    assert dt < TIGHT and dr < TIGHT, (dt, dr)
+    co, so = [0, len(corner), 2 * len(corner)], [0, len(surf), 2 * len(surf)]
+    poses, st, _ = gpu.match_scan2map_batch(np.concatenate([corner, corner]), co, np.concatenate([surf, surf]), so, [g, g])
+    assert np.all(st == s) and np.array_equal(poses[0], pose_g) and np.array_equal(poses[1], pose_g)
 
 
 def test_batch_equals_single_and_is_deterministic(gpu, oracle):
