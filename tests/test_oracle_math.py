@@ -95,6 +95,22 @@ def test_lstsq_5x3_matches_numpy(oracle):
         assert np.allclose(x / np.linalg.norm(x), want / np.linalg.norm(want), atol=1e-9)
 
 
+def test_lstsq_reproduces_the_eigen_tutorial_example_and_its_rank_rule(oracle):
+    """The example Eigen's own tutorial prints for `A.colPivHouseholderQr().solve(b)` ("Linear algebra and
+    decompositions": A = [1 2 3; 4 5 6; 7 8 10], b = [3 3 4], solution -2 1 1), padded to five rows with zero
+    equations, which leave a least-squares solution unchanged; and the rank-revealing side of the decomposition the
+    matcher relies on for degenerate neighbourhoods: a column of zeros (five map points with z = 0 exactly) is
+    rank 2 and gets a zero component, which is what ColPivHouseholderQR::solve returns for the dropped pivot."""
+    A = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 10], [0, 0, 0], [0, 0, 0]], np.float64)
+    b = np.array([3, 3, 4, 0, 0], np.float64)
+    x, rank = oracle.lstsq_5x3(A, b)
+    assert rank == 3 and np.allclose(x, [-2.0, 1.0, 1.0], atol=1e-12)
+    P = np.array([[1.0, 2.0, 0], [2.0, -1.0, 0], [0.5, 0.25, 0], [3.0, 1.0, 0], [-1.0, 4.0, 0]])
+    x, rank = oracle.lstsq_5x3(P, -np.ones(5))
+    want = np.linalg.lstsq(P[:, :2], -np.ones(5), rcond=None)[0]
+    assert rank == 2 and x[2] == 0.0 and np.allclose(x[:2], want, atol=1e-12)
+
+
 def test_edge_and_plane_fit_match_numpy(oracle):
     rng = np.random.default_rng(7)
     n_line = n_not = 0
