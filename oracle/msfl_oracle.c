@@ -4,7 +4,8 @@
  * Plain C99 restatement of the MSF_LOAM scan-matching hot path.  Every function cites the
  * reference file:line it follows (paths relative to /root/reference).  PARITY UNPINNED by the
  * reference's own tests (it has none on this path); pinned instead by the independent
- * numpy/scipy formulations in tests/.
+ * numpy/scipy formulations in tests/, whose trust-region loop in turn reproduces the run the
+ * Ceres tutorial prints for Powell's function (tests/test_oracle_lm_trajectory.py).
  *
  * Compile with -ffp-contract=off: the reference is built for generic x86-64 (no FMA), and the
  * f32 kNN distances / curvature sums below must round exactly like that build.

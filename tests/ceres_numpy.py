@@ -108,10 +108,10 @@ def evaluate(corr, x, opt, want_jacobian=True):
     return cost, np.concatenate(res), (np.vstack(jac) if want_jacobian else None)
 
 
-def gradient_max_norm(x, g):
+def gradient_max_norm(x, g, plus_fn=None):
     """TrustRegionMinimizer::ComputeGradientMaxNorm... (trust_region_minimizer.cc): for an unconstrained problem
     the projected-gradient form |x - Plus(x, -g)|_inf."""
-    return np.max(np.abs(x - plus(x, -g)))
+    return np.max(np.abs(x - (plus_fn or plus)(x, -g)))
 
 
 class Trace:
@@ -123,22 +123,28 @@ class Trace:
         self.initial_cost = self.final_cost = 0.0
 
 
-def solve(corr, x0, opt=Options):
+def solve(corr, x0, opt=Options, evaluate_fn=None, plus_fn=None, n_tangent=6):
     """TrustRegionMinimizer::Minimize (trust_region_minimizer.cc) with LevenbergMarquardtStrategy
-    (levenberg_marquardt_strategy.cc) and TrustRegionStepEvaluator (monotonic steps)."""
+    (levenberg_marquardt_strategy.cc) and TrustRegionStepEvaluator (monotonic steps).
+
+    `evaluate_fn(corr, x, opt) -> (cost, residuals, jacobian)`, `plus_fn(x, delta)` and `n_tangent` replace the scan
+    matcher's problem by any other least-squares problem: the loop itself is then checked against a run Ceres
+    publishes (tests/test_oracle_lm_trajectory.py, Powell's function from the Ceres tutorial)."""
+    evaluate = evaluate_fn or globals()["evaluate"]
+    plus = plus_fn or globals()["plus"]
     tr = Trace()
     x = np.array(x0, dtype=np.float64)
-    if not any(int(c["kind"]) != 0 for c in corr):
+    if evaluate_fn is None and not any(int(c["kind"]) != 0 for c in corr):
         tr.termination = "empty"                        # Problem without residual blocks: parameters untouched
         return x, tr
     # ---- Init(): iteration 0 ----
     cost, r, J = evaluate(corr, x, opt)
     tr.initial_cost = tr.final_cost = cost
-    scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0))) if opt.jacobi_scaling else np.ones(6)     # fixed after iteration 0
+    scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0))) if opt.jacobi_scaling else np.ones(n_tangent)     # fixed after iteration 0
     g = J.T @ r                                          # gradient in the unscaled tangent space
     Js = J * scale
     x_norm = np.sqrt(x @ x)
-    gmax = gradient_max_norm(x, g)
+    gmax = gradient_max_norm(x, g, plus)
     if gmax <= opt.gradient_tolerance:
         tr.termination = "gradient"
         return x, tr
@@ -159,7 +165,7 @@ def solve(corr, x0, opt=Options):
         D = np.sqrt(diagonal / radius)
         reuse_diagonal = True
         A = np.vstack([Js, np.diag(D)])
-        b = np.concatenate([-r, np.zeros(6)])
+        b = np.concatenate([-r, np.zeros(n_tangent)])
         step, *_ = np.linalg.lstsq(A, b, rcond=None)
         valid = bool(np.all(np.isfinite(step)))
         used_radius = radius
@@ -196,7 +202,7 @@ def solve(corr, x0, opt=Options):
             Js = J * scale
             g = J.T @ r
             x_norm = np.sqrt(x @ x)
-            gmax = gradient_max_norm(x, g)
+            gmax = gradient_max_norm(x, g, plus)
             radius = min(radius / max(1.0 / 3.0, 1.0 - (2.0 * rel - 1.0) ** 3), opt.max_trust_region_radius)
             decrease_factor, reuse_diagonal, step_successful = 2.0, False, True
             tr.successful_steps += 1
