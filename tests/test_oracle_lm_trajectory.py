@@ -178,3 +178,26 @@ def test_the_restated_minimizer_reproduces_the_run_ceres_publishes_for_powells_f
     assert t.termination == "gradient" and t.final_cost < 1e-12        # "Gradient tolerance reached" in the printed report
     for got, want in zip(x, (0.000146222, -1.46222e-05, 2.40957e-05, 2.40957e-05)):       # the printed final parameters
         assert digits(got, want, 5e-6), (got, want)
+
+
+def test_the_restated_minimizer_reproduces_the_ceres_hello_world_run():
+    """The other run the Ceres tutorial prints in full ("Hello World!": one residual f(x) = 10 - x from x = 0.5):
+    cost 4.512500e+01 -> 4.511598e-07 -> 5.012552e-16, steps 9.50e+00 and 9.50e-04, step quality 1.00, radius 3e4 -> 9e4.
+    With a single column the numbers isolate the damping itself: the first step falls short of 9.5 by exactly the
+    factor 1 / (1 + 1 / radius) that D = sqrt(diag(J'J) / radius) on the Jacobi-scaled column gives."""
+    def f(_, x, opt, want_jacobian=True):
+        r = np.array([10.0 - x[0]])
+        return 0.5 * float(r @ r), r, np.array([[-1.0]])
+
+    class Defaults(cn.Options):
+        max_num_iterations = 50
+
+    x, t = cn.solve(None, np.array([0.5]), Defaults, evaluate_fn=f, plus_fn=lambda x, d: x + d, n_tangent=1)
+    assert t.initial_cost == 45.125
+    for k, (cost, step, radius_after) in enumerate([(4.511598e-07, 9.50e+00, 3.00e+04), (5.012552e-16, 9.50e-04, 9.00e+04)]):
+        assert t.accepted[k] == 1
+        assert abs(t.cost[k] - cost) <= 5e-7 * cost, (k, t.cost[k])
+        assert abs(t.step_norm[k] - step) <= 5e-3 * step
+        assert abs(t.rel_decrease[k] - 1.0) < 5e-3
+        assert abs(t.radius[k + 1] - radius_after) <= 1e-9 * radius_after
+    assert abs(x[0] - 10.0) < 1e-6
