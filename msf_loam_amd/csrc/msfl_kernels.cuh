@@ -361,7 +361,11 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
   }
 }
 
-// Sub-wave form of the same search (build switch MSFL_KNN_SUBWAVE, measurement only): 16 lanes per query.
+#ifndef MSFL_KNN_SUBWAVE
+#define MSFL_KNN_SUBWAVE 0
+#endif
+constexpr int kKnnSubLanes = MSFL_KNN_SUBWAVE > 1 ? MSFL_KNN_SUBWAVE : 16;   // lanes per query of the sub-wave form (4, 8, 16 or 32)
+// Sub-wave form of the same search (build switch MSFL_KNN_SUBWAVE = lanes per query, measurement only).
 __device__ __forceinline__ void knn5_grid_sub(const GridDesc& g, const float4* __restrict__ sorted,
                                           const int* __restrict__ cell_start, float3 q, float max_sq_dist, Top5& t,
                                           int& n_cand, int sl) {   // the 16 lanes of a query call this with the same q; sl = lane within the group
@@ -405,7 +409,7 @@ __device__ __forceinline__ void knn5_grid_sub(const GridDesc& g, const float4* _
     const int s = cell_start[row + a], e = cell_start[row + b + 1];
     n_cand += e - s;
     const int lane = (int)(threadIdx.x & 63);
-    for (int i0 = s; i0 < e; i0 += 16) {
+    for (int i0 = s; i0 < e; i0 += kKnnSubLanes) {
       const int i = i0 + sl;
       const bool in = i < e;
       float4 m = sorted[in ? i : s];
@@ -414,9 +418,9 @@ __device__ __forceinline__ void knn5_grid_sub(const GridDesc& g, const float4* _
       const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)__float_as_int(m.w);
       const bool pass = in && __float_as_uint(d) <= (unsigned int)(t.k4 >> 32) && key < t.k4;
       const unsigned long long bm = __ballot(pass);
-      unsigned grp = (unsigned)(bm >> (lane & 48)) & 0xffffu;
+      unsigned grp = (unsigned)(bm >> (lane & ~(kKnnSubLanes - 1))) & (unsigned)((1ull << kKnnSubLanes) - 1ull);
       while (grp) {
-        const int src = (lane & 48) + __ffs((int)grp) - 1;
+        const int src = (lane & ~(kKnnSubLanes - 1)) + __ffs((int)grp) - 1;
         const unsigned lo = __shfl((unsigned)key, src), hi = __shfl((unsigned)(key >> 32), src);
         top5_insert(t, __uint_as_float(hi), (int)lo);
         grp &= grp - 1;
@@ -626,17 +630,14 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   }
 }
 
-#ifndef MSFL_KNN_SUBWAVE
-#define MSFL_KNN_SUBWAVE 0
-#endif
-// 16 lanes per query, four queries per wavefront (the shape of assoc_scan2scan_grid_kernel); plain branch only.
+// kKnnSubLanes lanes per query (16: four queries per wavefront (the shape of assoc_scan2scan_grid_kernel); plain branch only.
 __global__ void __launch_bounds__(64)
 knn5_scan2map_sub_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
                          const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
                          const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
                          const int* __restrict__ pos_c, const int* __restrict__ pos_s, float max_sq_dist, int* __restrict__ nn) {
-  const int sl = threadIdx.x & 15;
-  const int g_raw = bv.rec_begin + (int)((blockIdx.x * 64 + threadIdx.x) >> 4);
+  const int sl = threadIdx.x & (kKnnSubLanes - 1);
+  const int g_raw = bv.rec_begin + (int)((blockIdx.x * 64 + threadIdx.x) / kKnnSubLanes);
   if (g_raw >= bv.n_records) return;                          // whole groups leave together
   const int g = g_raw;
   const int b = find_scan(bv.rec_off, bv.n_scans, g);
