@@ -19,6 +19,16 @@
 
 namespace msfl {
 
+// Record arithmetic shared by the three association kernels (one-wavefront, tiled brute-force, column grid), which must
+// agree bit for bit: unit vectors by v * rsqrt(v.v) (v_rsq_f64 + two Newton steps; the zero vector of two coincident
+// points stays zero) and the centroid of the three plane points by a multiplication.  The IEEE square root, the three
+// divisions by it and the three divisions by 3 were a tenth of the column-grid kernel's instructions per query.
+__device__ __forceinline__ d3 odom_unit(d3 v) { return normalized_rsq(v); }
+__device__ __forceinline__ d3 odom_centroid3(d3 a, d3 b, d3 c) {
+  const double third = 1.0 / 3.0;
+  return mk3((a.x + b.x + c.x) * third, (a.y + b.y + c.y) * third, (a.z + b.z + c.z) * third);
+}
+
 struct OdomView {
   // previous scan (targets), concatenated over the batch
   const float4* last_ls; const uint16_t* last_ls_ring; const int* last_ls_off;
@@ -165,7 +175,7 @@ assoc_scan2scan_kernel(BatchView bv, OdomView ov, const double* __restrict__ pos
         if (min2 >= 0) {                                                   // :143-162
           const float4 a = tp[closest], c = tp[min2];
           const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z);
-          N = normalized(A - Bp);
+          N = odom_unit(A - Bp);
           C = A;
         }
       } else {
@@ -173,8 +183,8 @@ assoc_scan2scan_kernel(BatchView bv, OdomView ov, const double* __restrict__ pos
           const float4 a = tp[closest], c = tp[min2], e = tp[min3];
           const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z),
                    Cp = mk3((double)e.x, (double)e.y, (double)e.z);
-          N = normalized(cross(A - Bp, A - Cp));
-          C = mk3((A.x + Bp.x + Cp.x) / 3, (A.y + Bp.y + Cp.y) / 3, (A.z + Bp.z + Cp.z) / 3);
+          N = odom_unit(cross(A - Bp, A - Cp));
+          C = odom_centroid3(A, Bp, Cp);
         }
       }
       if (edge_pass) { out[0] = C.x; out[1] = C.y; out[2] = C.z; out[3] = N.x; out[4] = N.y; out[5] = N.z; }
@@ -288,7 +298,7 @@ assoc_scan2scan_wave_kernel(BatchView bv, OdomView ov, const double* __restrict_
     if (min2 >= 0) {
       const float4 a = tp[closest], c = tp[min2];
       const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z);
-      N = normalized(A - Bp); C = A;
+      N = odom_unit(A - Bp); C = A;
     }
     out[0] = C.x; out[1] = C.y; out[2] = C.z; out[3] = N.x; out[4] = N.y; out[5] = N.z;
   } else {
@@ -296,8 +306,8 @@ assoc_scan2scan_wave_kernel(BatchView bv, OdomView ov, const double* __restrict_
       const float4 a = tp[closest], c = tp[min2], e = tp[min3];
       const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z),
                Cp = mk3((double)e.x, (double)e.y, (double)e.z);
-      N = normalized(cross(A - Bp, A - Cp));
-      C = mk3((A.x + Bp.x + Cp.x) / 3, (A.y + Bp.y + Cp.y) / 3, (A.z + Bp.z + Cp.z) / 3);
+      N = odom_unit(cross(A - Bp, A - Cp));
+      C = odom_centroid3(A, Bp, Cp);
     }
     out[0] = N.x; out[1] = N.y; out[2] = N.z; out[3] = dot(N, C);
   }
@@ -683,7 +693,7 @@ __device__ __forceinline__ void odom_grid_query(const BatchView& bv, const OdomV
     if (min2 >= 0) {                                             // :143-162
       const float4 a = tp[closest], c = tp[min2];
       const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z);
-      N = normalized(A - Bp);
+      N = odom_unit(A - Bp);
       C = A;
     }
     out[0] = C.x; out[1] = C.y; out[2] = C.z; out[3] = N.x; out[4] = N.y; out[5] = N.z;
@@ -693,8 +703,8 @@ __device__ __forceinline__ void odom_grid_query(const BatchView& bv, const OdomV
     const float4 a = tp[closest], c = tp[min2], e = tp[min3];
     const d3 A = mk3((double)a.x, (double)a.y, (double)a.z), Bp = mk3((double)c.x, (double)c.y, (double)c.z),
              Cp = mk3((double)e.x, (double)e.y, (double)e.z);
-    N = normalized(cross(A - Bp, A - Cp));
-    C = mk3((A.x + Bp.x + Cp.x) / 3, (A.y + Bp.y + Cp.y) / 3, (A.z + Bp.z + Cp.z) / 3);
+    N = odom_unit(cross(A - Bp, A - Cp));
+    C = odom_centroid3(A, Bp, Cp);
   }
   out[0] = N.x; out[1] = N.y; out[2] = N.z; out[3] = dot(N, C);
 }
