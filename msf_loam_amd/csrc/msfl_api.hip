@@ -324,12 +324,6 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
                          (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
                          (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
                          h->prm.map_knn_max_sq_dist, dv, nn);
-    else if (MSFL_KNN_SUBWAVE)
-      hipLaunchKernelGGL(knn5_scan2map_sub_kernel, dim3(div_up(n_rec * kKnnSubLanes, 64)), dim3(64), 0, st, bv, d_poses, d_status,
-                         (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
-                         (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
-                         (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
-                         h->prm.map_knn_max_sq_dist, nn);
     else
       hipLaunchKernelGGL(knn5_scan2map_kernel<false>, grid, block, 0, st, bv, d_poses, d_status,
                          (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),

@@ -905,9 +905,6 @@ __global__ void __launch_bounds__(256) voxel_batch_run_centroid_kernel(VoxelBatc
 // Two instantiations: <16, 768> (1024 threads, 12 288 runs: 96 KB of records + 48 KB of order buffers, one workgroup
 // per CU) for clouds like a less-flat list, <4, 512> (256 threads, 2 048 runs, 26 KB: six workgroups per CU) when every
 // cloud of the batch has at most kVoxSmallPoints points (corner lists).
-#ifndef MSFL_VOX_EXP
-#define MSFL_VOX_EXP 0       // timing experiments only (stop after phase 1 / 3 / 4)
-#endif
 constexpr int kVoxMaxPoints = 65535;                // the first point of a run is a 16-bit number
 constexpr int kVoxSmallPoints = 4096;
 
@@ -1020,9 +1017,6 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   }
   if (my_flag) atomicMax(&s_flag, my_flag);
   __syncthreads();
-#if MSFL_VOX_EXP == 1
-  if (tid == 0) { flags[b] = 0; m_out[b] = 0; } return;
-#endif
   // ---- phase 2 ----
   int flag = s_flag;
   const int mb0 = s_bb[0], mb1 = s_bb[1], mb2 = s_bb[2];
@@ -1099,9 +1093,6 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
     cur ^= 1;
     __syncthreads();
   }
-#if MSFL_VOX_EXP == 2
-  if (tid == 0) { flags[b] = 0; m_out[b] = 0; } return;
-#endif
   // ---- phase 4: voxel heads (positions in the sorted order) into the other order buffer ----
   unsigned short* heads_at = s_ord[cur ^ 1];
   if (tid == 0) s_total = 0;
@@ -1123,9 +1114,6 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   const int m = s_total;
   // ---- phase 5: one thread per voxel ----
   float4* out = staging + v.off[b];
-#if MSFL_VOX_EXP == 3
-  if (tid == 0) { flags[b] = 0; m_out[b] = 0; } return;
-#endif
   // Every voxel starts from its first run's sum (phase 1); only later runs (7 % of the voxels of a less-flat list have
   // any) are read again and added point by point.  Small voxels: one thread each.  A voxel close to the sensor can hold
   // hundreds of points (a 0.4 m cube on the ground two metres out takes ~60 points of every ring that crosses it): a

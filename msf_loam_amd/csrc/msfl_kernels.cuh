@@ -361,108 +361,6 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
   }
 }
 
-#ifndef MSFL_KNN_SUBWAVE
-#define MSFL_KNN_SUBWAVE 0
-#endif
-constexpr int kKnnSubLanes = MSFL_KNN_SUBWAVE > 1 ? MSFL_KNN_SUBWAVE : 16;   // lanes per query of the sub-wave form (4, 8, 16 or 32)
-// Sub-wave form of the same search (build switch MSFL_KNN_SUBWAVE = lanes per query, measurement only).
-__device__ __forceinline__ void knn5_grid_sub(const GridDesc& g, const float4* __restrict__ sorted,
-                                          const int* __restrict__ cell_start, float3 q, float max_sq_dist, Top5& t,
-                                          int& n_cand, int sl) {   // the 16 lanes of a query call this with the same q; sl = lane within the group
-  top5_init(t, max_sq_dist);
-  const float ux = (q.x - g.ox) * g.inv_cell_x, uy = (q.y - g.oy) * g.inv_cell, uz = (q.z - g.oz) * g.inv_cell;
-  const int cx = grid_coord(q.x, g.ox, g.inv_cell_x, g.dx);
-  const int cy = grid_coord(q.y, g.oy, g.inv_cell, g.dy);
-  const int cz = grid_coord(q.z, g.oz, g.inv_cell, g.dz);
-  const int xs = max(cx - kGridXSub, 0), xe = min(cx + kGridXSub, g.dx - 1);
-  if (xs > xe) return;
-  const float cell2 = g.cell2;
-  // per-axis lower bounds for the three y and three z cell offsets, computed once
-  const float gy0 = axis_gap(uy, cy - 1), gy1 = axis_gap(uy, cy), gy2 = axis_gap(uy, cy + 1);
-  const float gz0 = axis_gap(uz, cz - 1), gz1 = axis_gap(uz, cz), gz2 = axis_gap(uz, cz + 1);
-  const float cellx2 = g.cellx2;
-  // squared lower bounds of the kGridXSub cells left of / right of the query cell, outermost first: they
-  // are the same for all nine rows, so the per-row trimming is two adds and two compares per side
-  float gxa[kGridXSub], gxb[kGridXSub];
-#pragma unroll
-  for (int k = 0; k < kGridXSub; k++) {
-    const float ga = axis_gap(ux, xs + k), gb = axis_gap(ux, xe - k);
-    gxa[k] = ga * ga * cellx2; gxb[k] = gb * gb * cellx2;
-  }
-  const msfl_f2 qxy = {q.x, q.y};
-  // Visit order of the 9 (dy, dz) rows, PER QUERY: centre, then the two side rows on the query's near sides (smaller
-  // gap first), the two far side rows, the near-near diagonal, the two mixed diagonals, the far-far diagonal.  Any
-  // order is exact (a row is only skipped on a lower bound); this one makes the 64 queries of a wavefront need the
-  // same loop POSITIONS: with a fixed (-y, +y, -z, +z) order each position ran for the ~19 lanes whose near side it
-  // happened to be and cost the longest of their ranges, now the first two positions carry nearly all of that work
-  // and the later ones are skipped by the whole wavefront; the 5th-best distance also tightens sooner.
-  const bool y_lo = gy0 <= gy2, z_lo = gz0 <= gz2;                 // near side: the smaller gap
-  const int sy = y_lo ? -1 : 1, sz = z_lo ? -1 : 1;
-  const float g_ny = y_lo ? gy0 : gy2, g_fy = y_lo ? gy2 : gy0;
-  const float g_nz = z_lo ? gz0 : gz2, g_fz = z_lo ? gz2 : gz0;
-  const bool ny_first = g_ny <= g_nz, fy_first = g_fy <= g_fz;
-  const bool e_first = g_ny * g_ny + g_fz * g_fz <= g_fy * g_fy + g_nz * g_nz;   // (near y, far z) before (far y, near z)
-  // candidates of the cells [a, b] of a row: x-adjacent cells are contiguous in the sorted array
-  // the group's 16 lanes stride the row's range; candidates below the running 5th-best (one ballot, this group's 16 bits)
-  // are broadcast one at a time and inserted by every lane of the group into its (replicated) top-5
-  auto scan = [&](int row, int a, int b) __attribute__((always_inline)) {
-    const int s = cell_start[row + a], e = cell_start[row + b + 1];
-    n_cand += e - s;
-    const int lane = (int)(threadIdx.x & 63);
-    for (int i0 = s; i0 < e; i0 += kKnnSubLanes) {
-      const int i = i0 + sl;
-      const bool in = i < e;
-      float4 m = sorted[in ? i : s];
-      asm volatile("" : "+v"(m.w));
-      const float d = l2_simple_pk(m, qxy, q.z);
-      const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)__float_as_int(m.w);
-      const bool pass = in && __float_as_uint(d) <= (unsigned int)(t.k4 >> 32) && key < t.k4;
-      const unsigned long long bm = __ballot(pass);
-      unsigned grp = (unsigned)(bm >> (lane & ~(kKnnSubLanes - 1))) & (unsigned)((1ull << kKnnSubLanes) - 1ull);
-      while (grp) {
-        const int src = (lane & ~(kKnnSubLanes - 1)) + __ffs((int)grp) - 1;
-        const unsigned lo = __shfl((unsigned)key, src), hi = __shfl((unsigned)(key >> 32), src);
-        top5_insert(t, __uint_as_float(hi), (int)lo);
-        grp &= grp - 1;
-      }
-    }
-  };
-#pragma unroll
-  for (int r = 0; r < 9; r++) {
-    int dy, dz; float gy, gz;
-    if (r == 0) { dy = 0; dz = 0; gy = gy1; gz = gz1; }
-    else if (r == 1 || r == 2) {                                    // near side rows
-      const bool yrow = (r == 1) == ny_first;
-      dy = yrow ? sy : 0; dz = yrow ? 0 : sz; gy = yrow ? g_ny : gy1; gz = yrow ? gz1 : g_nz;
-    } else if (r == 3 || r == 4) {                                  // far side rows
-      const bool yrow = (r == 3) == fy_first;
-      dy = yrow ? -sy : 0; dz = yrow ? 0 : -sz; gy = yrow ? g_fy : gy1; gz = yrow ? gz1 : g_fz;
-    } else if (r == 5) { dy = sy; dz = sz; gy = g_ny; gz = g_nz; }
-    else if (r == 6 || r == 7) {                                    // mixed diagonals
-      const bool e = (r == 6) == e_first;                           // e: (near y, far z)
-      dy = e ? sy : -sy; dz = e ? -sz : sz; gy = e ? g_ny : g_fy; gz = e ? g_fz : g_nz;
-    } else { dy = -sy; dz = -sz; gy = g_fy; gz = g_fz; }
-    const int y = cy + dy, z = cz + dz;
-    if (y < 0 || y >= g.dy || z < 0 || z >= g.dz) continue;
-    const float row2 = (gy * gy + gz * gz) * cell2;
-    const int row = (z * g.dy + y) * g.dx;
-    const float d4 = top5_d4(t);
-    if (row2 > d4) continue;                  // d4 is the acceptance gate until five neighbours are known
-    // trim the x range: drop end cells whose lower bound exceeds the 5th-best distance
-    // a cell is dropped when its lower bound exceeds d4; the bounds shrink towards the query, so count the
-    // leading run of dropped cells on each side
-    int a = xs, b = xe;
-    bool da = true, db = true;
-#pragma unroll
-    for (int k = 0; k < kGridXSub; k++) {
-      da = da && (row2 + gxa[k] > d4); a += da ? 1 : 0;
-      db = db && (row2 + gxb[k] > d4); b -= db ? 1 : 0;
-    }
-    if (a > b) continue;                      // only near the grid border: every remaining cell is out of reach
-    scan(row, a, b);
-  }
-}
-
 struct FitOut { d3 C, N; bool ok; };
 
 // mapping_scan_matcher.cc:130-151
@@ -580,7 +478,7 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   if (g >= bv.n_records) return;
   const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);
   int* out = nn + 5 * (size_t)g;
-  if (status[b] != 0) { out[0] = -1; return; }
+  if (status[b] != 0) { out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1; return; }
   const int local = g - bv.rec_off[b];
   const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
   const bool is_edge = local < nc;
@@ -626,41 +524,7 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
     out[0] = po[(unsigned int)t.k0]; out[1] = po[(unsigned int)t.k1]; out[2] = po[(unsigned int)t.k2];
     out[3] = po[(unsigned int)t.k3]; out[4] = po[(unsigned int)t.k4];       // nearest first
   } else {
-    out[0] = -1;
-  }
-}
-
-// kKnnSubLanes lanes per query (16: four queries per wavefront (the shape of assoc_scan2scan_grid_kernel); plain branch only.
-__global__ void __launch_bounds__(64)
-knn5_scan2map_sub_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
-                         const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
-                         const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
-                         const int* __restrict__ pos_c, const int* __restrict__ pos_s, float max_sq_dist, int* __restrict__ nn) {
-  const int sl = threadIdx.x & (kKnnSubLanes - 1);
-  const int g_raw = bv.rec_begin + (int)((blockIdx.x * 64 + threadIdx.x) / kKnnSubLanes);
-  if (g_raw >= bv.n_records) return;                          // whole groups leave together
-  const int g = g_raw;
-  const int b = find_scan(bv.rec_off, bv.n_scans, g);
-  int* out = nn + 5 * (size_t)g;
-  if (status[b] != 0) { if (sl == 0) out[0] = -1; return; }
-  const int local = g - bv.rec_off[b];
-  const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
-  const bool is_edge = local < nc;
-  const int fi = is_edge ? bv.corner_off[b] + local : bv.surf_off[b] + (local - nc);
-  const float4 f = is_edge ? bv.corner[fi] : bv.surf[fi];
-  const pose7 T = load_pose(poses + 7 * b);
-  const float3 q = transform_point_f32(T, f.x, f.y, f.z);
-  Top5 t;
-  int n_cand = 0;
-  if (is_edge) { const GridDesc gc = *gcp; knn5_grid_sub(gc, map_c, cs_c, q, max_sq_dist, t, n_cand, sl); }
-  else { const GridDesc gs = *gsp; knn5_grid_sub(gs, map_s, cs_s, q, max_sq_dist, t, n_cand, sl); }
-  if (sl != 0) return;
-  if ((unsigned int)t.k4 != 0xffffffffu && (double)top5_d4(t) < (double)max_sq_dist) {
-    const int* po = is_edge ? pos_c : pos_s;
-    out[0] = po[(unsigned int)t.k0]; out[1] = po[(unsigned int)t.k1]; out[2] = po[(unsigned int)t.k2];
-    out[3] = po[(unsigned int)t.k3]; out[4] = po[(unsigned int)t.k4];
-  } else {
-    out[0] = -1;
+    out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1;   // all five: the fit kernel loads them unconditionally
   }
 }
 
@@ -753,9 +617,6 @@ struct DevMatchInfo {   // mirrors msfl_match_info
   double initial_cost[2], final_cost[2];
 };
 
-#ifndef MSFL_LM_EXP
-#define MSFL_LM_EXP 0     // timing experiments only, wrong results (2: streamed plane records loaded but not evaluated, 3: evaluated without loads)
-#endif
 constexpr int kAcc = 28;   // cost + g[6] + H upper[21]
 
 // ---- robustified normal equations, one residual row at a time ----------------------------------------------
@@ -952,9 +813,6 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   // pass becomes latency bound instead).
   for (; i < ns; i += BLOCK) {
     const double* r4 = recp + 4 * (size_t)i;
-#if MSFL_LM_EXP == 3
-    const d3 N = mk3(0.6, 0.0, 0.8); const double d0 = 1.0 + 1e-3 * i; d3 p = mk3(1.0 + i, 2.0, 3.0);
-#else
     const d3 N = mk3(r4[0], r4[1], r4[2]); const double d0 = r4[3];
     d3 p;
     if (pprime) { const size_t q = (size_t)(nc + i); p = mk3(pprime[3 * q], pprime[3 * q + 1], pprime[3 * q + 2]); }
@@ -966,12 +824,7 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
         pc.px[i] = f.x; pc.py[i] = f.y; pc.pz[i] = f.z;
       }
     }
-#endif
-#if MSFL_LM_EXP == 2
-    acc[0] += N.x + d0 + p.x; n_plane++;
-#else
     plane_row(N, d0, p);
-#endif
   }
   LM_T(t_planes_done);
 }

@@ -37,7 +37,14 @@ __device__ __forceinline__ d3 normalized(d3 v) {
 
 // 1 / x for x in a benign range (no scaling / fix-up steps of the IEEE division sequence): v_rcp_f64 + two Newton
 // steps, within an ulp or two of the correctly rounded quotient
+// Build switch -DMSFL_IEEE_DIV=1 restores the IEEE division / square root everywhere (parity runs: a decision sitting
+// within an ulp of a threshold then rounds like the oracle's); the fast forms also fall back to the IEEE sequence for
+// arguments outside [1e-280, 1e280], where the unscaled Newton steps would lose bits or overflow.
+#ifndef MSFL_IEEE_DIV
+#define MSFL_IEEE_DIV 0
+#endif
 __device__ __forceinline__ double fast_rcp(double x) {
+  if (MSFL_IEEE_DIV || !(fabs(x) > 1e-280 && fabs(x) < 1e280)) return 1.0 / x;
   double y = __builtin_amdgcn_rcp(x);
   double e = __builtin_fma(-x, y, 1.0);
   y = __builtin_fma(y, e, y);
@@ -46,6 +53,7 @@ __device__ __forceinline__ double fast_rcp(double x) {
 }
 // 1 / sqrt(x), x > 0 and far from the denormal range: v_rsq_f64 + two Newton steps
 __device__ __forceinline__ double fast_rsqrt(double x) {
+  if (MSFL_IEEE_DIV || !(x > 1e-280 && x < 1e280)) return 1.0 / sqrt(x);
   double y = __builtin_amdgcn_rsq(x);
   const double hx = 0.5 * x;
   double e = __builtin_fma(-hx * y, y, 0.5);
@@ -56,7 +64,7 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 
 __device__ __forceinline__ d3 normalized_rsq(d3 v) {
   const double z = dot(v, v);
-  if (z > 1e-280 && z < 1e280) { const double s = fast_rsqrt(z); return mk3(v.x * s, v.y * s, v.z * s); }
+  if (!MSFL_IEEE_DIV && z > 1e-280 && z < 1e280) { const double s = fast_rsqrt(z); return mk3(v.x * s, v.y * s, v.z * s); }
   return normalized(v);
 }
 

@@ -374,9 +374,10 @@ def test_voxel_pair_call_equals_the_two_batch_calls(gpu, oracle):
     rng = np.random.default_rng(31)
     sc = common.scans(5)
     feats = [oracle.extract_features(p, r) for p, r, _, _ in sc]
-    def run(feats, extra_b=None):
+    def run(feats, extra_b=None, extra_a=None):
         sizes = [len(f["full"]) for f in feats]
         if extra_b is not None: sizes[2] = max(sizes[2], len(extra_b))
+        if extra_a is not None: sizes[3] = max(sizes[3], len(extra_a))
         off = np.cumsum([0] + sizes).astype(np.int32)
         n = int(off[-1])
         full = np.zeros((n, 4), np.float32); ia = np.zeros(n, np.int32); ib = np.zeros(n, np.int32)
@@ -387,6 +388,8 @@ def test_voxel_pair_call_equals_the_two_batch_calls(gpu, oracle):
             if b == 1: la = la[:0]
             if b == 2 and extra_b is not None:
                 full[off[b]:off[b] + len(extra_b)] = extra_b; lb = np.arange(len(extra_b), dtype=np.int32)
+            if b == 3 and extra_a is not None:
+                full[off[b]:off[b] + len(extra_a)] = extra_a; la = np.arange(len(extra_a), dtype=np.int32); lb = lb[lb < 0]
             ia[off[b]:off[b] + len(la)] = la; ca[b] = len(la)
             ib[off[b]:off[b] + len(lb)] = lb; cb[b] = len(lb)
         t = lambda a: torch.from_numpy(a).to(dev)
@@ -413,3 +416,6 @@ def test_voxel_pair_call_equals_the_two_batch_calls(gpu, oracle):
     assert oo[0][2] == oo[0][1]                                            # the empty list
     big = np.zeros((70000, 4), np.float32); big[:, :3] = rng.uniform(-25, 25, (70000, 3))
     run(feats, extra_b=big)
+    # list a alone above the limit (its fallback used to overwrite list b's pending read-back), then both lists
+    run(feats, extra_a=big)
+    run(feats, extra_b=big, extra_a=big[:66000])

@@ -102,10 +102,6 @@ def whole():
     extract(); voxel(); register()
 
 
-if os.environ.get("MSFL_PIPE_VOXEL_ONLY") == "1":           # phase experiments on the voxel filter (library built with -DMSFL_VOX_EXP=n)
-    extract(); voxel(); voxel()
-    print(json.dumps({"ms_voxel": 1e3 * timed(voxel, STEPS), "runs_note": "corner 0.2 m + surf 0.4 m calls"}))
-    sys.exit(0)
 whole()                                                     # warm-up (allocations)
 whole()
 import gc
