@@ -32,5 +32,8 @@ def test_plain_gpus_2_launches_two_ranks():
                          cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
     err = out.stderr + out.stdout
     assert "launch with torch.distributed.run" not in err
-    assert err.count("bench.py needs a GPU") >= 2, err[-2000:]
+    # the elastic agent SIGTERMs the other rank as soon as the first one exits, so only ONE rank is certain to get its
+    # message out; that two ranks were started shows in the agent's failure report (one entry per rank)
+    assert err.count("bench.py needs a GPU") >= 1, err[-2000:]
+    assert "local_rank: 0" in err and "local_rank: 1" in err, err[-2000:]
     assert out.returncode != 0
