@@ -5,20 +5,22 @@
 //   HybridGrid::InsertScan          (:503-521)  append to cells, VoxelGrid-filter the touched cells
 //   HybridGrid::GetSurroundedCloud  (:470-501)  union of the cells around the transformed scan points
 //
-// GPU formulation.  The whole map is ONE point array sorted by a 63-bit key
-//     key = cell(iz,iy,ix: 14 bits each) << 21 | voxel-in-cell(rz,ry,rx: 7 bits each)
-// so a cell is a contiguous run and the voxels of a cell appear in pcl::VoxelGrid's output order
-// (z major, x minor).  Because a filtered cell holds one centroid per voxel and the centroid of a
-// single point is the point itself, re-filtering an untouched cell is the identity: InsertScan is
-// therefore "append, stable-sort everything by key (old points first), one centroid per key run"
-// — one rocPRIM radix sort + two light kernels, no per-cell containers, no pointer chasing.
-// A map point keeps the CELL of the run it was created from (the reference keeps a point in the cell
-// container it was pushed into and does not re-derive the cell from the centroid's coordinates); the
-// voxel part of its key is re-derived from its coordinates whenever an insert touches its cell, because
-// the reference's per-cell filter bins by coordinates (grid_rekey_touched_kernel).
-// Cost per insert is O(map + scan) (one sort over everything); merging the sorted scan into the
-// sorted map and re-filtering only the runs that received points would make it O(scan).
-// GetSurroundedCloud marks cells through a binary search over the sorted unique cell keys.
+// GPU formulation (round 3: insert cost proportional to the SCAN, not to the map).
+//   * The points live in one POOL; a cell is a slab [start, start + count) of it, its points in
+//     pcl::VoxelGrid's output order (voxel index z-major, x-minor).
+//   * A CELL TABLE sorted by the 42-bit cell key (iz, iy, ix: 14 bits each, the reference's +-8192
+//     limit, hybrid_grid.cc:460) holds {key, start, count}.
+//   * InsertScan sorts only the NEW points by (cell, voxel) key, finds the cells they touch, and
+//     rebuilds exactly those cells: one workgroup per touched cell merges the cell's old points
+//     (voxel re-derived from their coordinates, because the reference re-runs the filter over the
+//     cell's own cloud, :513-520) with the new ones in LDS, one centroid per voxel run, f32 sums in
+//     the order pcl's CentroidPoint sees (old points first, then the new ones in scan order).  The
+//     rebuilt cells go to fresh slabs at the top of the pool, the old slabs become garbage, the
+//     cell table is rebuilt by a merge (O(cells)); the pool is compacted when it fills up.
+//     Untouched cells are never read or written.
+//   * Every kernel takes its sizes from a device-resident GridState / device counters and is launched
+//     over a host-known upper bound, so a whole insert (or surround query) is stream-ordered with no
+//     host round trip: the per-scan SLAM step (msfl_slam.inc) chains them without synchronising.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,11 +32,29 @@ namespace msfl {
 constexpr int kGridCellBits = 14;                 // +-8192 cells, the reference's hard limit (hybrid_grid.cc:460)
 constexpr int kGridVoxBits = 7;
 constexpr unsigned long long kGridBadKey = ~0ull;
+constexpr unsigned kGridVoxMask = (1u << (3 * kGridVoxBits)) - 1u;
 
 struct GridStoreDesc {
   float resolution;       // 3.0
   float inv_leaf;         // 1 / leaf, f32 like pcl::VoxelGrid::inverse_leaf_size_
   double leaf;
+};
+
+// device-resident bookkeeping of one map store
+struct GridState {
+  int n_cells;            // live cells
+  int n_points;           // live points
+  int pool_top;           // first free pool slot
+  int epoch;              // surround queries stamp hit cells with it (no clearing pass)
+  // --- the insert in flight (reset by grid_begin_kernel) ---
+  int bad;                // a new point lies outside the +-8192-cell range: the insert is dropped, map unchanged
+  int overflow;           // pool / cell-table capacity exceeded (the host sizes both so that this cannot happen)
+  int n_touched;          // cells the scan touches
+  int n_new_cells;        // of which not yet in the table
+  int work;               // pool slots the rebuilt cells take (their slabs' capacities)
+  int delta_points;       // sum over touched cells of (points after - points before)
+  int n_big;              // touched cells the small rebuild kernel left to the large one
+  int surround_total;     // points delivered by the last surround query
 };
 
 // HybridGridBase::GetCellIndex (:422-426): lround(double(p / resolution)), division in f32
@@ -48,6 +68,12 @@ __device__ __forceinline__ unsigned long long grid_cell_key(int ix, int iy, int 
   return ((unsigned long long)(iz + lim) << (2 * kGridCellBits)) | ((unsigned long long)(iy + lim) << kGridCellBits) |
          (unsigned long long)(ix + lim);
 }
+__device__ __forceinline__ void grid_cell_of_key(unsigned long long cell, int& ix, int& iy, int& iz) {
+  const int lim = 1 << (kGridCellBits - 1);
+  ix = (int)(cell & ((1u << kGridCellBits) - 1u)) - lim;
+  iy = (int)((cell >> kGridCellBits) & ((1u << kGridCellBits) - 1u)) - lim;
+  iz = (int)(cell >> (2 * kGridCellBits)) - lim;
+}
 
 // voxel coordinate of pcl::VoxelGrid (floor(p * inv_leaf) in f32) relative to a per-cell base that
 // only has to be monotone: rel = k - (floor((c - 0.5) * resolution / leaf) - 2)
@@ -56,13 +82,43 @@ __device__ __forceinline__ int grid_vox_rel(float v, int c, const GridStoreDesc&
   const int base = (int)floor(((double)c - 0.5) * (double)d.resolution / d.leaf) - 2;
   return k - base;
 }
+// 21-bit voxel-in-cell key (z major) of a point filed under cell (ix, iy, iz).  An old centroid is the mean of points
+// of its cell, so its voxel lies inside the cell's range up to rounding; the clamp only keeps a stray value addressable.
+__device__ __forceinline__ unsigned grid_vox_key(float4 p, int ix, int iy, int iz, const GridStoreDesc& d) {
+  const int lim = (1 << kGridVoxBits) - 1;
+  const int rx = min(max(grid_vox_rel(p.x, ix, d), 0), lim), ry = min(max(grid_vox_rel(p.y, iy, d), 0), lim),
+            rz = min(max(grid_vox_rel(p.z, iz, d), 0), lim);
+  return ((unsigned)rz << (2 * kGridVoxBits)) | ((unsigned)ry << kGridVoxBits) | (unsigned)rx;
+}
 
-// full 63-bit key of a map-frame point; kGridBadKey when out of range (caller reports MSFL_CAPACITY)
-__global__ void __launch_bounds__(256) grid_point_key_kernel(const float4* __restrict__ pts, int n, GridStoreDesc d,
-                                                              unsigned long long* __restrict__ keys, int* __restrict__ bad) {
+__device__ __forceinline__ int grid_dev_n(int n_cap, const int* __restrict__ n_dev) {
+  return n_dev ? min(max(*n_dev, 0), n_cap) : n_cap;
+}
+
+// ---- insert, step 0: reset the per-insert fields --------------------------------------------------------------------
+__global__ void grid_begin_kernel(GridState* __restrict__ st) {
+  st->bad = 0; st->overflow = 0; st->n_touched = 0; st->n_new_cells = 0; st->work = 0; st->delta_points = 0; st->n_big = 0;
+}
+
+// ---- insert, step 1: (optional) rigid transform + 63-bit key of every new point -------------------------------------
+// pose != null: p <- TransformPoint(pose, p) (laser_mapping.cc:24-31 / rigid_transform.h:131-137: f32 -> f64 -> q p + t -> f32),
+// written to xf (what the rest of the insert reads); pose == null: xf is not touched and the caller passes pts as xf.
+// Slots at and beyond the device-side count get the bad key so that they sort to the end.
+__global__ void __launch_bounds__(256)
+grid_key_kernel(const float4* __restrict__ pts, int n_cap, const int* __restrict__ n_dev, const double* __restrict__ pose,
+                float4* __restrict__ xf, GridStoreDesc d, unsigned long long* __restrict__ keys, int* __restrict__ vals,
+                GridState* __restrict__ st) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
+  if (i >= n_cap) return;
+  const int n = grid_dev_n(n_cap, n_dev);
+  vals[i] = i;
+  if (i >= n) { keys[i] = kGridBadKey; return; }
+  float4 p = pts[i];
+  if (pose) {
+    const float3 q = transform_point_f32(load_pose(pose), p.x, p.y, p.z);
+    p = make_float4(q.x, q.y, q.z, p.w);
+    xf[i] = p;
+  }
   const int ix = grid_cell_index(p.x, d.resolution), iy = grid_cell_index(p.y, d.resolution), iz = grid_cell_index(p.z, d.resolution);
   unsigned long long key = grid_cell_key(ix, iy, iz);
   if (key != kGridBadKey) {
@@ -72,80 +128,38 @@ __global__ void __launch_bounds__(256) grid_point_key_kernel(const float4* __res
     else key = (key << (3 * kGridVoxBits)) | ((unsigned long long)rz << (2 * kGridVoxBits)) | ((unsigned long long)ry << kGridVoxBits) |
                (unsigned long long)rx;
   }
-  if (key == kGridBadKey) *bad = 1;
+  if (key == kGridBadKey) st->bad = 1;              // a non-finite coordinate lands here too (lround of NaN / inf is out of range)
   keys[i] = key;
 }
 
-// cell part of the new scan's keys (sorted afterwards: the set of cells this insert touches)
-__global__ void __launch_bounds__(256) grid_cell_of_key_kernel(const unsigned long long* __restrict__ keys, int n,
-                                                                unsigned long long* __restrict__ cells) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) cells[i] = keys[i] >> (3 * kGridVoxBits);
-}
-
-// The reference re-runs the voxel filter over every cell the scan touched (hybrid_grid.cc:513-520): an old centroid of
-// such a cell is binned by its COORDINATES again (an f32 centroid can round onto the next voxel's boundary and then
-// merges with that voxel's content), while it stays in the cell container it was pushed into and nothing moves in the
-// cells the scan does not touch.  So: old map points whose cell is among `touched` (sorted, duplicates allowed) get the
-// voxel part of their key re-derived from their coordinates, relative to their STORED cell; all other keys stay.
-__global__ void __launch_bounds__(256) grid_rekey_touched_kernel(const float4* __restrict__ pts, int n, GridStoreDesc d,
-                                                                  const unsigned long long* __restrict__ touched, int n_touched,
-                                                                  unsigned long long* __restrict__ keys, int* __restrict__ bad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long cell = keys[i] >> (3 * kGridVoxBits);
-  int lo = 0, hi = n_touched;                               // first entry >= cell
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (touched[mid] < cell) lo = mid + 1; else hi = mid; }
-  if (lo == n_touched || touched[lo] != cell) return;
-  const int lim_c = 1 << (kGridCellBits - 1);
-  const int ix = (int)(cell & ((1u << kGridCellBits) - 1u)) - lim_c, iy = (int)((cell >> kGridCellBits) & ((1u << kGridCellBits) - 1u)) - lim_c,
-            iz = (int)(cell >> (2 * kGridCellBits)) - lim_c;
-  const float4 p = pts[i];
-  const int rx = grid_vox_rel(p.x, ix, d), ry = grid_vox_rel(p.y, iy, d), rz = grid_vox_rel(p.z, iz, d);
-  const int lim = 1 << kGridVoxBits;
-  if (rx < 0 || rx >= lim || ry < 0 || ry >= lim || rz < 0 || rz >= lim) { *bad = 1; return; }
-  keys[i] = (cell << (3 * kGridVoxBits)) | ((unsigned long long)rz << (2 * kGridVoxBits)) | ((unsigned long long)ry << kGridVoxBits) |
-            (unsigned long long)rx;
-}
-
-// head flags of key runs (voxels) and of cell runs in the sorted key array
-__global__ void __launch_bounds__(256) grid_flag_kernel(const unsigned long long* __restrict__ keys, int n,
-                                                         int* __restrict__ vox_head, int* __restrict__ cell_head) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long k = keys[i];
-  const bool first = (i == 0);
-  vox_head[i] = (first || k != keys[i - 1]) ? 1 : 0;
-  cell_head[i] = (first || (k >> (3 * kGridVoxBits)) != (keys[i - 1] >> (3 * kGridVoxBits))) ? 1 : 0;
-}
-
-// one thread per voxel head: centroid of the run in sorted (= arrival) order, f32 accumulators
-// (pcl CentroidPoint); writes the filtered point, its key, and records cell starts.
+// ---- insert, step 2 (after the stable sort of the new keys): heads of the cell runs ----------------------------------
 __global__ void __launch_bounds__(256)
-grid_centroid_kernel(const float4* __restrict__ pts, const int* __restrict__ order, const unsigned long long* __restrict__ keys,
-                     const int* __restrict__ vox_head, const int* __restrict__ vox_pos, const int* __restrict__ cell_head,
-                     const int* __restrict__ cell_pos, int n, float4* __restrict__ out_pts, unsigned long long* __restrict__ out_keys,
-                     unsigned long long* __restrict__ cell_keys, int* __restrict__ cell_start,
-                     const int* __restrict__ bad, int* __restrict__ result) {
+grid_touch_flag_kernel(const unsigned long long* __restrict__ skeys, int n_cap, const int* __restrict__ n_dev, int* __restrict__ head) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == n - 1) { result[0] = vox_pos[i]; result[1] = cell_pos[i]; result[2] = *bad; }   // {points, cells, out-of-range flag}: one read-back
-  if (i >= n || !vox_head[i]) return;
-  const unsigned long long k = keys[i];
-  float sx = 0.f, sy = 0.f, sz = 0.f, st = 0.f;
-  int j = i;
-  for (; j < n && keys[j] == k; j++) {
-    const float4 p = pts[order[j]];
-    sx += p.x; sy += p.y; sz += p.z; st += p.w;
+  if (i >= n_cap) return;
+  const int n = grid_dev_n(n_cap, n_dev);
+  int h = 0;
+  if (i < n) {
+    const unsigned long long c = skeys[i] >> (3 * kGridVoxBits);
+    h = (i == 0 || c != (skeys[i - 1] >> (3 * kGridVoxBits))) ? 1 : 0;
   }
-  const float c = (float)(j - i);
-  const int o = vox_pos[i] - 1;                    // inclusive scan -> index of this voxel in the new map
-  out_pts[o] = make_float4(sx / c, sy / c, sz / c, st / c);
-  out_keys[o] = k;
-  if (cell_head[i]) {
-    const int ci = cell_pos[i] - 1;
-    cell_keys[ci] = k >> (3 * kGridVoxBits);
-    cell_start[ci] = o;
-  }
+  head[i] = h;
+}
+
+// ---- insert, step 3 (after the inclusive scan of the heads): the sorted list of touched cells ------------------------
+// t_key[t] = cell key, t_ns[t] = first position of the cell's new points in the sorted order (t_ns[n_touched] = n).
+// A dropped insert (bad point) touches nothing.
+__global__ void __launch_bounds__(256)
+grid_touch_list_kernel(const unsigned long long* __restrict__ skeys, const int* __restrict__ head, const int* __restrict__ tpos, int n_cap,
+                       const int* __restrict__ n_dev, unsigned long long* __restrict__ t_key, int* __restrict__ t_ns, GridState* __restrict__ st) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cap) return;
+  const int n = grid_dev_n(n_cap, n_dev);
+  const bool dropped = st->bad != 0;
+  if (i == 0 && (n == 0 || dropped)) { st->n_touched = 0; t_ns[0] = 0; }
+  if (i >= n || dropped) return;
+  if (head[i]) { const int t = tpos[i] - 1; t_key[t] = skeys[i] >> (3 * kGridVoxBits); t_ns[t] = i; }
+  if (i == n - 1) { st->n_touched = tpos[i]; t_ns[tpos[i]] = n; }
 }
 
 __device__ __forceinline__ int grid_find_cell(const unsigned long long* __restrict__ cell_keys, int n_cells, unsigned long long key) {
@@ -158,14 +172,232 @@ __device__ __forceinline__ int grid_find_cell(const unsigned long long* __restri
   }
   return -1;
 }
+__device__ __forceinline__ int grid_lower_bound(const unsigned long long* __restrict__ keys, int n, unsigned long long key) {
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
 
-// GetSurroundedCloud pass 1: mark the cells hit by pose_f32 * p + (i,j,k) metres
+// LDS capacities of the two rebuild instantiations (entries = old + new points of one cell, padded to a power of two)
+constexpr int kGridSmallCap = 2048;               // 256 threads, 16 KB: the common cell (tens to hundreds of points)
+constexpr int kGridLargeCap = 16384;              // 1024 threads, 128 KB; beyond that the sort runs in a global scratch slab
+__host__ __device__ __forceinline__ int grid_pow2_at_least(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// ---- insert, step 4: plan — one workgroup walks the touched cells: table lookup, slab sizes, prefix sums --------------
+// t_old[t]   = index in the current cell table (-1: new cell)
+// t_woff[t]  = pool slot of the rebuilt cell's slab (capacity old + new, + scratch for cells beyond the LDS capacity)
+// t_rank[t]  = number of NEW cells among touched cells [0, t)
+__global__ void __launch_bounds__(1024)
+grid_plan_kernel(const unsigned long long* __restrict__ cell_keys, const int* __restrict__ cell_cnt, const unsigned long long* __restrict__ t_key,
+                 const int* __restrict__ t_ns, int* __restrict__ t_old, int* __restrict__ t_woff, int* __restrict__ t_rank,
+                 int pool_cap, int cell_cap, GridState* __restrict__ st) {
+  __shared__ int s_a[16], s_b[16];
+  __shared__ int s_carry_a, s_carry_b;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = st->n_touched, nc = st->n_cells, top = st->pool_top;
+  if (tid == 0) { s_carry_a = 0; s_carry_b = 0; }
+  __syncthreads();
+  for (int base = 0; base < nt; base += 1024) {
+    const int t = base + tid;
+    int alloc = 0, is_new = 0, e = -1;
+    if (t < nt) {
+      e = grid_find_cell(cell_keys, nc, t_key[t]);
+      const int cap = (e >= 0 ? cell_cnt[e] : 0) + (t_ns[t + 1] - t_ns[t]);
+      alloc = cap > kGridLargeCap ? cap + grid_pow2_at_least(cap) / 2 : cap;      // 8-byte sort entries in 16-byte slots
+      is_new = e < 0 ? 1 : 0;
+    }
+    int ia = alloc, ib = is_new;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int ua = __shfl_up(ia, o), ub = __shfl_up(ib, o); if (lane >= o) { ia += ua; ib += ub; } }
+    if (lane == 63) { s_a[wave] = ia; s_b[wave] = ib; }
+    __syncthreads();
+    int pa = s_carry_a + ia - alloc, pb = s_carry_b + ib - is_new;
+    for (int w = 0; w < wave; w++) { pa += s_a[w]; pb += s_b[w]; }
+    if (t < nt) { t_old[t] = e; t_woff[t] = top + pa; t_rank[t] = pb; }
+    __syncthreads();
+    if (tid == 1023) { s_carry_a = pa + alloc; s_carry_b = pb + is_new; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    t_rank[nt] = s_carry_b;
+    st->work = s_carry_a; st->n_new_cells = s_carry_b;
+    if ((long long)top + s_carry_a > (long long)pool_cap || nc + s_carry_b > cell_cap) { st->overflow = 1; st->n_touched = 0; st->work = 0; st->n_new_cells = 0; }
+  }
+}
+
+// ---- insert, step 5: rebuild the touched cells ------------------------------------------------------------------------
+// Sort entries are (voxel key << 32 | ordinal): ordinals [0, n_old) = the cell's current points in their stored order,
+// [n_old, E) = its new points in sorted-new order (= scan order inside a voxel: the sort of the new keys is stable), so
+// the unique 64-bit keys sort into exactly the order pcl's stable view gives: per voxel old first, then new in arrival order.
+template <int THREADS>
+__device__ __forceinline__ void grid_bitonic(unsigned long long* __restrict__ s, int P, int k_first) {
+  for (int k = k_first; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < (P >> 1); i += THREADS) {
+        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;       // the pair (lo, lo + j)
+        const bool up = (lo & k) == 0;
+        const unsigned long long a = s[lo], b = s[hi];
+        if ((a > b) == up) { s[lo] = b; s[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int THREADS, int LDS_CAP, bool LARGE>
+__global__ void __launch_bounds__(THREADS)
+grid_rebuild_kernel(const float4* __restrict__ pool_in, float4* __restrict__ pool_out, const int* __restrict__ cell_start,
+                    const int* __restrict__ cell_cnt, const float4* __restrict__ xf, const unsigned long long* __restrict__ skeys,
+                    const int* __restrict__ svals, const unsigned long long* __restrict__ t_key, const int* __restrict__ t_ns,
+                    const int* __restrict__ t_old, const int* __restrict__ t_woff, int* __restrict__ t_cnt, GridStoreDesc d,
+                    GridState* __restrict__ st) {
+  __shared__ unsigned long long s_ent[LDS_CAP];
+  __shared__ int s_wsum[THREADS / 64];
+  __shared__ int s_carry, s_unsorted;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = st->n_touched;
+  if (LARGE && st->n_big == 0) return;
+  for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+    const int e = t_old[t];
+    const int n_old = e >= 0 ? cell_cnt[e] : 0, o_start = e >= 0 ? cell_start[e] : 0;
+    const int ns = t_ns[t], n_new = t_ns[t + 1] - ns;
+    const int E = n_old + n_new;
+    if (LARGE ? E <= kGridSmallCap : E > kGridSmallCap) {            // the other instantiation's cell
+      if (!LARGE && tid == 0) atomicAdd(&st->n_big, 1);
+      continue;
+    }
+    const int P = grid_pow2_at_least(E);
+    const int woff = t_woff[t];
+    // entries beyond the LDS capacity (LARGE only): the sort runs in the scratch half of the cell's slab
+    unsigned long long* ent = s_ent;
+    if (LARGE && P > LDS_CAP) ent = reinterpret_cast<unsigned long long*>(pool_out + woff + E);
+    int cx, cy, cz;
+    grid_cell_of_key(t_key[t], cx, cy, cz);
+    if (tid == 0) { s_unsorted = 0; s_carry = 0; }
+    __syncthreads();
+    // fill: old points ascending at the front, new points DESCENDING at the back, padding (max key) between them.  The new
+    // keys are sorted; the old ones are too unless a centroid's f32 rounding moved it into another voxel, so the sequence
+    // is bitonic and ONE merge network (log2 P steps) sorts it; an unsorted old part takes the full network instead.
+    for (int i = tid; i < P; i += THREADS) {
+      unsigned long long key = ~0ull;
+      if (i < n_old) {
+        const float4 p = pool_in[o_start + i];
+        const unsigned v = grid_vox_key(p, cx, cy, cz, d);
+        key = ((unsigned long long)v << 32) | (unsigned)i;
+        if (i + 1 < n_old) { const unsigned vn = grid_vox_key(pool_in[o_start + i + 1], cx, cy, cz, d); if (vn < v) s_unsorted = 1; }
+      } else if (i >= P - n_new) {
+        const int j = P - 1 - i;                                       // new point j (sorted-new order)
+        key = ((unsigned long long)((unsigned)skeys[ns + j] & kGridVoxMask) << 32) | (unsigned)(n_old + j);
+      }
+      ent[i] = key;
+    }
+    __syncthreads();
+    grid_bitonic<THREADS>(ent, P, s_unsorted ? 2 : P);
+    // voxel runs: heads, their ranks (block scan over chunks of THREADS entries), one thread per head walks its run
+    float4* out = pool_out + woff;
+    for (int base = 0; base < E; base += THREADS) {
+      const int i = base + tid;
+      unsigned v = 0; bool head = false;
+      if (i < E) {
+        v = (unsigned)(ent[i] >> 32);
+        head = i == 0 || v != (unsigned)(ent[i - 1] >> 32);
+      }
+      const unsigned long long hm = __ballot(head);
+      const int before = __popcll(hm & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wsum[wave] = __popcll(hm);
+      __syncthreads();
+      int r = s_carry + before;
+      for (int w = 0; w < wave; w++) r += s_wsum[w];
+      if (head) {
+        float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+        int j = i;
+        for (; j < E && (unsigned)(ent[j] >> 32) == v; j++) {
+          const int ord = (int)(unsigned)ent[j];
+          const float4 p = ord < n_old ? pool_in[o_start + ord] : xf[svals[ns + ord - n_old]];
+          sx += p.x; sy += p.y; sz += p.z; sw += p.w;
+        }
+        const float c = (float)(j - i);
+        out[r] = make_float4(sx / c, sy / c, sz / c, sw / c);
+      }
+      __syncthreads();
+      if (tid == THREADS - 1) s_carry = r + (head ? 1 : 0);
+      __syncthreads();
+    }
+    if (tid == 0) { const int R = s_carry; t_cnt[t] = R; atomicAdd(&st->delta_points, R - n_old); }
+    __syncthreads();
+  }
+}
+
+// ---- insert, step 6: the new cell table = old table merged with the new cells; touched cells point at their new slabs ---
 __global__ void __launch_bounds__(256)
-grid_mark_kernel(const float4* __restrict__ scan, int n, const double* __restrict__ pose, float resolution,
-                 const unsigned long long* __restrict__ cell_keys, int n_cells, int* __restrict__ hit) {
+grid_commit_kernel(const unsigned long long* __restrict__ keys_in, const int* __restrict__ start_in, const int* __restrict__ cnt_in,
+                   const int* __restrict__ stamp_in, unsigned long long* __restrict__ keys_out, int* __restrict__ start_out,
+                   int* __restrict__ cnt_out, int* __restrict__ stamp_out, const unsigned long long* __restrict__ t_key,
+                   const int* __restrict__ t_old, const int* __restrict__ t_woff, const int* __restrict__ t_rank, const int* __restrict__ t_cnt,
+                   int bound, const GridState* __restrict__ st) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bound) return;
+  const int nc = st->n_cells, nt = st->n_touched;
+  if (i < nc) {                                                        // an existing cell moves up by the new cells before it
+    const unsigned long long k = keys_in[i];
+    const int p = grid_lower_bound(t_key, nt, k);
+    const bool touched = p < nt && t_key[p] == k;
+    const int o = i + t_rank[p];
+    keys_out[o] = k;
+    start_out[o] = touched ? t_woff[p] : start_in[i];
+    cnt_out[o] = touched ? t_cnt[p] : cnt_in[i];
+    stamp_out[o] = stamp_in[i];
+  } else if (i - nc < nt) {                                            // a touched cell that is new
+    const int t = i - nc;
+    if (t_old[t] >= 0) return;
+    const unsigned long long k = t_key[t];
+    const int o = grid_lower_bound(keys_in, nc, k) + t_rank[t];
+    keys_out[o] = k; start_out[o] = t_woff[t]; cnt_out[o] = t_cnt[t]; stamp_out[o] = 0;
+  }
+}
+
+// one thread: fold the insert into the state, publish {points, cells, pool_top, bad, overflow, work} for the host
+__global__ void grid_finish_kernel(GridState* __restrict__ st, int* __restrict__ report) {
+  st->n_cells += st->n_new_cells;
+  st->n_points += st->delta_points;
+  st->pool_top += st->work;
+  if (report) {
+    report[0] = st->n_points; report[1] = st->n_cells; report[2] = st->pool_top; report[3] = st->bad; report[4] = st->overflow;
+    report[5] = st->n_touched; report[6] = st->work; report[7] = st->surround_total;
+  }
+}
+
+// ---- pool compaction / dump: the live cells back to back in table order -----------------------------------------------
+// (after an exclusive scan of the counts into new_start)
+__global__ void __launch_bounds__(256)
+grid_zero_tail_kernel(int* __restrict__ cnt, int bound, const GridState* __restrict__ st) {   // counts beyond n_cells read as 0 by the scan
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < bound && i >= st->n_cells) cnt[i] = 0;
+}
+__global__ void __launch_bounds__(256)
+grid_compact_kernel(const float4* __restrict__ pool_in, const int* __restrict__ start, const int* __restrict__ cnt, const int* __restrict__ new_start,
+                    float4* __restrict__ out, int capacity, int* __restrict__ start_out, int bound, GridState* __restrict__ st, int set_top) {
+  const int nc = st->n_cells;
+  for (int c = blockIdx.x; c < min(nc, bound); c += gridDim.x) {
+    const int s = start[c], m = cnt[c], o = new_start[c];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) if (o + i < capacity) out[o + i] = pool_in[s + i];
+    if (start_out && threadIdx.x == 0) start_out[c] = o;
+  }
+  if (set_top && blockIdx.x == 0 && threadIdx.x == 0) st->pool_top = st->n_points;
+}
+
+// ---- GetSurroundedCloud ---------------------------------------------------------------------------------------------
+__global__ void grid_epoch_kernel(GridState* __restrict__ st) { st->epoch += 1; st->surround_total = 0; }
+
+// pass 1: stamp the cells hit by pose_f32 * p + (i,j,k) metres
+__global__ void __launch_bounds__(256)
+grid_mark_kernel(const float4* __restrict__ scan, const int* __restrict__ idx, int n_cap, const int* __restrict__ n_dev,
+                 const double* __restrict__ pose, float resolution, const unsigned long long* __restrict__ cell_keys, int* __restrict__ stamp,
+                 const GridState* __restrict__ st) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const float4 p = scan[t];
+  if (t >= grid_dev_n(n_cap, n_dev)) return;
+  const int n_cells = st->n_cells, epoch = st->epoch;
+  const float4 p = scan[idx ? idx[t] : t];
   const float nrm = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
   if ((double)nrm > 60.0) return;                                   // kDist (:474, :532)
   // pose.cast<float>() * point: Eigen Quaternionf _transformVector + translation, all f32 (:478)
@@ -183,30 +415,31 @@ grid_mark_kernel(const float4* __restrict__ scan, int n, const double* __restric
                                                      grid_cell_index(wz + (float)k, resolution));
         if (key == kGridBadKey) continue;
         const int c = grid_find_cell(cell_keys, n_cells, key);
-        if (c >= 0) hit[c] = 1;                                     // TryInsertGrid (:524-529)
+        if (c >= 0 && stamp[c] != epoch) stamp[c] = epoch;          // TryInsertGrid (:524-529)
       }
 }
 
-// per cell: number of points to emit (0 when not hit)
-__global__ void __launch_bounds__(256) grid_emit_count_kernel(const int* __restrict__ hit, const int* __restrict__ cell_start, int n_cells,
-                                                               int n_points, int* __restrict__ cnt) {
+// per cell: number of points to emit (0 when not hit, 0 beyond the live cells)
+__global__ void __launch_bounds__(256)
+grid_emit_count_kernel(const int* __restrict__ stamp, const int* __restrict__ cell_cnt, int bound, int* __restrict__ cnt, const GridState* __restrict__ st) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n_cells) return;
-  const int e = (c + 1 < n_cells) ? cell_start[c + 1] : n_points;
-  cnt[c] = hit[c] ? (e - cell_start[c]) : 0;
+  if (c >= bound) return;
+  cnt[c] = (c < st->n_cells && stamp[c] == st->epoch) ? cell_cnt[c] : 0;
 }
 
-// copy the hit cells, ascending cell order; one workgroup-stride loop per cell chunk
-__global__ void __launch_bounds__(256) grid_emit_kernel(const float4* __restrict__ pts, const int* __restrict__ cell_start,
-                                                         const int* __restrict__ cnt, const int* __restrict__ out_off, int n_cells,
-                                                         int capacity, float4* __restrict__ out) {
-  const int c = blockIdx.x;
-  if (c >= n_cells) return;
-  const int m = cnt[c];
-  if (m == 0) return;
-  const int s = cell_start[c], o = out_off[c];
-  for (int i = threadIdx.x; i < m; i += blockDim.x)
-    if (o + i < capacity) out[o + i] = pts[s + i];
+// copy the hit cells in ascending cell order (after the exclusive scan of cnt into off); *n_out = total
+__global__ void __launch_bounds__(256)
+grid_emit_kernel(const float4* __restrict__ pool, const int* __restrict__ cell_start, const int* __restrict__ cnt, const int* __restrict__ off,
+                 int bound, int capacity, float4* __restrict__ out, int* __restrict__ n_out, GridState* __restrict__ st) {
+  const int nc = min(st->n_cells, bound);
+  for (int c = blockIdx.x; c < nc; c += gridDim.x) {
+    const int m = cnt[c];
+    if (c == nc - 1 && threadIdx.x == 0) { const int total = off[c] + m; st->surround_total = total; if (n_out) *n_out = total; }
+    if (m == 0) continue;
+    const int s = cell_start[c], o = off[c];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) if (o + i < capacity) out[o + i] = pool[s + i];
+  }
+  if (nc == 0 && blockIdx.x == 0 && threadIdx.x == 0) { st->surround_total = 0; if (n_out) *n_out = 0; }
 }
 
 }  // namespace msfl

@@ -21,12 +21,24 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-enum Op { FMA_F32 = 0, PK_MUL_F32, PK_ADD_F32, CNDMASK, CMP_U64, FMA_F64, ADD_U32, N_OPS };
-static const char* kOpName[N_OPS] = {"v_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_cndmask_b32", "v_cmp_lt_u64", "v_fma_f64", "v_add_u32"};
+enum Op { FMA_F32 = 0, PK_MUL_F32, PK_ADD_F32, CNDMASK, CMP_U64, FMA_F64, ADD_U32, CNDMASK_SGPR, CNDMASK_VCC_ONCE, BFI_B32, MIN_U32, MED3_U32, AND_B32, MOV_B32, CMP_F32, CMP_U32, ADD_F32, MUL_F32, LSHL_ADD_U64, MAX_F32, CNDMASK_E64_VCC, CMP_U64_SGPR, CNDMASK_VCC_DISTINCT, N_OPS };
+static const char* kOpName[N_OPS] = {"v_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_cndmask_b32(vcc,cmp/32)", "v_cmp_lt_u64", "v_fma_f64", "v_add_u32", "v_cndmask_b32_e64(sgpr)", "v_cndmask_b32(vcc const)", "v_bfi_b32", "v_min_u32", "v_med3_u32", "v_and_b32", "v_mov_b32", "v_cmp_lt_f32", "v_cmp_lt_u32", "v_add_f32", "v_mul_f32", "v_lshl_add_u64", "v_max_f32", "v_cndmask_b32_e64(vcc)", "v_cmp_lt_u64_e64(sgpr dst)", "v_cndmask_b32(vcc, dst!=src)"};
 
 #define REP4(x) x x x x
 #define REP8(x) REP4(x) REP4(x)
 #define REP32(x) REP8(x) REP8(x) REP8(x) REP8(x)
+
+
+#define GEN_OPP(PRE, INSTR_DEP, INSTR_IND)                                                                                        \
+  {                                                                                                                          \
+    unsigned bi = __float_as_uint(b), ci = __float_as_uint(c);                                                               \
+    unsigned* ai = reinterpret_cast<unsigned*>(a);                                                                           \
+    if (DEP) asm volatile(PRE REP32(INSTR_DEP) : "+v"(ai[0]) : "v"(bi), "v"(ci) : "vcc", "s20", "s21");                             \
+    else asm volatile(PRE REP4(INSTR_IND) : "+v"(ai[0]), "+v"(ai[1]), "+v"(ai[2]), "+v"(ai[3]), "+v"(ai[4]), "+v"(ai[5]), "+v"(ai[6]), "+v"(ai[7]) \
+                      : "v"(bi), "v"(ci) : "vcc", "s20", "s21");                                                             \
+  }
+#define GEN_OP(INSTR_DEP, INSTR_IND) GEN_OPP("", INSTR_DEP, INSTR_IND)
+#define IND8(op, tail) op " %0, %0" tail "\n" op " %1, %1" tail "\n" op " %2, %2" tail "\n" op " %3, %3" tail "\n" op " %4, %4" tail "\n" op " %5, %5" tail "\n" op " %6, %6" tail "\n" op " %7, %7" tail "\n"
 
 // 32 instructions per call; DEP: all on accumulator 0, else round-robin over 8 accumulators
 template <int OP, bool DEP>
@@ -67,6 +79,43 @@ __device__ __forceinline__ void block32(float (&a)[8], f2 (&p)[8], double (&d)[8
     else asm volatile(REP4("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"
                            "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n")
                       : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]) : "v"(bd), "v"(cd));
+  } else if (OP == CNDMASK_SGPR) {
+    GEN_OPP("s_mov_b64 s[20:21], 0x55555555\n", "v_cndmask_b32_e64 %0, %0, %1, s[20:21]\n", IND8("v_cndmask_b32_e64", ", %8, s[20:21]"))
+  } else if (OP == CNDMASK_VCC_ONCE) {
+    GEN_OPP("s_mov_b64 vcc, 0x55555555\n", "v_cndmask_b32 %0, %0, %1, vcc\n", IND8("v_cndmask_b32", ", %8, vcc"))
+  } else if (OP == CNDMASK_E64_VCC) {
+    GEN_OPP("s_mov_b64 vcc, 0x55555555\n", "v_cndmask_b32_e64 %0, %0, %1, vcc\n", IND8("v_cndmask_b32_e64", ", %8, vcc"))
+  } else if (OP == CNDMASK_VCC_DISTINCT) {
+    GEN_OPP("s_mov_b64 vcc, 0x55555555\n", "v_cndmask_b32 %0, %1, %2, vcc\n", "v_cndmask_b32 %0, %8, %9, vcc\n v_cndmask_b32 %1, %8, %9, vcc\n v_cndmask_b32 %2, %8, %9, vcc\n v_cndmask_b32 %3, %8, %9, vcc\n v_cndmask_b32 %4, %8, %9, vcc\n v_cndmask_b32 %5, %8, %9, vcc\n v_cndmask_b32 %6, %8, %9, vcc\n v_cndmask_b32 %7, %8, %9, vcc\n")
+  } else if (OP == CMP_U64_SGPR) {
+    asm volatile(REP4("v_cmp_lt_u64_e64 s[20:21], %0, %1\n v_cmp_lt_u64_e64 s[22:23], %1, %2\n v_cmp_lt_u64_e64 s[20:21], %2, %3\n v_cmp_lt_u64_e64 s[22:23], %3, %4\n"
+                      "v_cmp_lt_u64_e64 s[20:21], %4, %5\n v_cmp_lt_u64_e64 s[22:23], %5, %6\n v_cmp_lt_u64_e64 s[20:21], %6, %7\n v_cmp_lt_u64_e64 s[22:23], %7, %0\n")
+                 : : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]) : "s20", "s21", "s22", "s23");
+  } else if (OP == BFI_B32) {
+    GEN_OP("v_bfi_b32 %0, %1, %0, %2\n", IND8("v_bfi_b32", ", %8, %9"))
+  } else if (OP == MIN_U32) {
+    GEN_OP("v_min_u32 %0, %0, %1\n", IND8("v_min_u32", ", %8"))
+  } else if (OP == MED3_U32) {
+    GEN_OP("v_med3_u32 %0, %0, %1, %2\n", IND8("v_med3_u32", ", %8, %9"))
+  } else if (OP == AND_B32) {
+    GEN_OP("v_and_b32 %0, %0, %1\n", IND8("v_and_b32", ", %8"))
+  } else if (OP == MOV_B32) {
+    GEN_OP("v_mov_b32 %0, %1\n", "v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n")
+  } else if (OP == CMP_F32) {
+    GEN_OP("v_cmp_lt_f32 vcc, %0, %1\n", "v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n v_cmp_lt_f32 vcc, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_cmp_lt_f32 vcc, %6, %8\n v_cmp_lt_f32 vcc, %7, %8\n")
+  } else if (OP == CMP_U32) {
+    GEN_OP("v_cmp_lt_u32 vcc, %0, %1\n", "v_cmp_lt_u32 vcc, %0, %8\n v_cmp_lt_u32 vcc, %1, %8\n v_cmp_lt_u32 vcc, %2, %8\n v_cmp_lt_u32 vcc, %3, %8\n v_cmp_lt_u32 vcc, %4, %8\n v_cmp_lt_u32 vcc, %5, %8\n v_cmp_lt_u32 vcc, %6, %8\n v_cmp_lt_u32 vcc, %7, %8\n")
+  } else if (OP == ADD_F32) {
+    GEN_OP("v_add_f32 %0, %0, %1\n", IND8("v_add_f32", ", %8"))
+  } else if (OP == MUL_F32) {
+    GEN_OP("v_mul_f32 %0, %0, %1\n", IND8("v_mul_f32", ", %8"))
+  } else if (OP == MAX_F32) {
+    GEN_OP("v_max_f32 %0, %0, %1\n", IND8("v_max_f32", ", %8"))
+  } else if (OP == LSHL_ADD_U64) {
+    if (DEP) asm volatile(REP32("v_lshl_add_u64 %0, %0, 0, %1\n") : "+v"(u[0]) : "v"(u[1]));
+    else asm volatile(REP4("v_lshl_add_u64 %0, %0, 0, %8\n v_lshl_add_u64 %1, %1, 0, %8\n v_lshl_add_u64 %2, %2, 0, %8\n v_lshl_add_u64 %3, %3, 0, %8\n"
+                           "v_lshl_add_u64 %4, %4, 0, %8\n v_lshl_add_u64 %5, %5, 0, %8\n v_lshl_add_u64 %6, %6, 0, %8\n v_lshl_add_u64 %7, %7, 0, %8\n")
+                      : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]) : "v"(d[0]));
   } else {
     unsigned bi = __float_as_uint(b);
     unsigned* ai = reinterpret_cast<unsigned*>(a);
@@ -131,8 +180,7 @@ Result run(int waves_per_simd, unsigned long long* d_clk, float* d_sink, int n_c
 
 template <int OP> void table(unsigned long long* d_clk, float* d_sink, int n_cu, FILE* js, bool& first) {
   for (int dep = 0; dep < 2; dep++) {
-    for (int w : {1, 2, 4, 8}) {
-      if (OP == FMA_F64 && w == 8) continue;                   // 16 f64 accumulators + pairs: keep the register count trivially safe
+    for (int w : {1, 2, 4}) {                                  // a workgroup holds at most 16 wavefronts = 4 per SIMD
       const Result r = dep ? run<OP, true>(w, d_clk, d_sink, n_cu) : run<OP, false>(w, d_clk, d_sink, n_cu);
       printf("%-14s %-11s waves/SIMD %d : %6.2f cyc/inst/wave  %5.2f cyc/inst/SIMD  clock %4.0f MHz  chip %7.1f G wave-inst/s\n", kOpName[OP],
              dep ? "dependent" : "independent", w, r.cyc_per_inst_wave, r.cyc_per_inst_simd, r.mhz, r.chip_ginst);
@@ -165,6 +213,22 @@ int main(int argc, char** argv) {
     table<CMP_U64>(d_clk, d_sink, n_cu, js, first);
     table<ADD_U32>(d_clk, d_sink, n_cu, js, first);
     table<FMA_F64>(d_clk, d_sink, n_cu, js, first);
+    table<CNDMASK_SGPR>(d_clk, d_sink, n_cu, js, first);
+    table<CNDMASK_VCC_ONCE>(d_clk, d_sink, n_cu, js, first);
+    table<BFI_B32>(d_clk, d_sink, n_cu, js, first);
+    table<MIN_U32>(d_clk, d_sink, n_cu, js, first);
+    table<MED3_U32>(d_clk, d_sink, n_cu, js, first);
+    table<AND_B32>(d_clk, d_sink, n_cu, js, first);
+    table<MOV_B32>(d_clk, d_sink, n_cu, js, first);
+    table<CMP_F32>(d_clk, d_sink, n_cu, js, first);
+    table<CMP_U32>(d_clk, d_sink, n_cu, js, first);
+    table<ADD_F32>(d_clk, d_sink, n_cu, js, first);
+    table<MUL_F32>(d_clk, d_sink, n_cu, js, first);
+    table<MAX_F32>(d_clk, d_sink, n_cu, js, first);
+    table<LSHL_ADD_U64>(d_clk, d_sink, n_cu, js, first);
+    table<CNDMASK_E64_VCC>(d_clk, d_sink, n_cu, js, first);
+    table<CNDMASK_VCC_DISTINCT>(d_clk, d_sink, n_cu, js, first);
+    table<CMP_U64_SGPR>(d_clk, d_sink, n_cu, js, first);
   }
   fprintf(js, "\n]}\n");
   if (js != stdout) fclose(js);
