@@ -82,7 +82,11 @@ class GpuBackend:
         return self.capi.Grid(self.mapper, 3.0, 0.2), self.capi.Grid(self.mapper, 3.0, 0.4)   # laser_mapping.cc:44-45,60-68
 
 
-def run(backend, world, poses_true, verbose=False):
+def run(backend, world, poses_true, verbose=False, maps_out=None):
+    # a backend may bring its own Rigid3d algebra (the oracle-driven loop of the tests uses the oracle's quaternion forms)
+    compose_ = getattr(backend, "compose", compose)
+    inverse_ = getattr(backend, "inverse", inverse)
+    transform_ = getattr(backend, "transform", transform_cloud)
     n = len(poses_true)
     odo2first = np.array([0, 0, 0, 0, 0, 0, 1.0])        # pose_scan2world_ (odometry frame = first scan)
     curr2last = np.array([0, 0, 0, 0, 0, 0, 1.0])
@@ -95,21 +99,21 @@ def run(backend, world, poses_true, verbose=False):
         t0 = time.perf_counter(); f = backend.extract(pts, ring); t1 = time.perf_counter()
         if last is not None:
             curr2last = backend.scan2scan(last, f, curr2last)                 # laser_odometry.cc:75 (guess = last delta)
-            odo2first = compose(odo2first, curr2last)                         # :79
+            odo2first = compose_(odo2first, curr2last)                        # :79
         t2 = time.perf_counter()
         corner = backend.voxel(f["full"][f["less_sharp"]], 0.2)               # laser_mapping.cc:264-270
         surf = backend.voxel(f["full"][f["less_flat"]], 0.4)
         t3 = time.perf_counter()
-        pose_map = compose(odom2map, odo2first)                               # TransformAssociateToMap, laser_mapping.h:55-57
+        pose_map = compose_(odom2map, odo2first)                              # TransformAssociateToMap, laser_mapping.h:55-57
         map_c = grid_c.get_surrounded(f["full"][f["less_sharp"]], pose_map)   # GetSurroundedCloud on the UN-down-sampled
         map_s = grid_s.get_surrounded(f["full"][f["less_flat"]], pose_map)    # feature clouds, laser_mapping.cc:273-278
         t3b = time.perf_counter()
         if len(map_c) > 10 and len(map_s) > 50:                               # gate, laser_mapping.cc:284-285
             pose_map = backend.scan2map(map_c, map_s, corner, surf, pose_map)
         t4 = time.perf_counter()
-        odom2map = compose(pose_map, inverse(odo2first))                      # TransformUpdate, laser_mapping.h:59-61
-        grid_c.insert_scan(transform_cloud(pose_map, f["full"][f["less_sharp"]]))   # InsertScan2Map, laser_mapping.cc:330-338
-        grid_s.insert_scan(transform_cloud(pose_map, f["full"][f["less_flat"]]))
+        odom2map = compose_(pose_map, inverse_(odo2first))                    # TransformUpdate, laser_mapping.h:59-61
+        grid_c.insert_scan(transform_(pose_map, f["full"][f["less_sharp"]]))   # InsertScan2Map, laser_mapping.cc:330-338
+        grid_s.insert_scan(transform_(pose_map, f["full"][f["less_flat"]]))
         t5 = time.perf_counter()
         last = f
         est.append(pose_map)
@@ -120,7 +124,45 @@ def run(backend, world, poses_true, verbose=False):
         if verbose and k % 20 == 0:
             print(k, synth.pose_error(pose_map, poses_true[k]), grid_c.size(), grid_s.size(), file=sys.stderr)
     m = max(n - 2, 1)
+    if maps_out is not None:
+        maps_out["corner"], maps_out["surf"] = grid_c.dump(), grid_s.dump()
     return np.array(est), {k: 1e3 * v / m for k, v in t_stage.items()}
+
+
+def run_slam(world, poses_true, pipelined=False, device=0, scans=None, verbose=False, maps_out=None):
+    """The same loop through the device-resident SLAM step (msfl_slam_add_scan): raw scan in, pose out, one
+    synchronisation per scan (pipelined=False) or none until the record is fetched one scan later (pipelined=True: the
+    odometry chain of scan k + 1 runs under the mapping chain of scan k, like the reference's two threads).
+    Returns (poses, records, wall-clock ms per scan over the scans after the second)."""
+    from msf_loam_amd import capi
+    n = len(poses_true)
+    if scans is None:
+        scans = [synth.make_scan(world, poses_true[k], synth.SEED + 5000 + k) for k in range(n)]
+    cap = max(len(p) for p, _ in scans)
+    slam = capi.Slam(device, max_scan_points=cap, max_rings=int(max(r.max() for _, r in scans)) + 1, pose_odom2map=poses_true[0])
+    recs = [None] * n
+    t_start = None
+    for k in range(n):
+        if k == 2:
+            t_start = time.perf_counter()
+        if pipelined:
+            slam.add_scan(*scans[k], wait=False)
+            if k >= 1:
+                recs[k - 1] = slam.result(k - 1)
+        else:
+            recs[k] = slam.add_scan(*scans[k])
+        if verbose and k % 50 == 0 and recs[max(k - 1, 0)] is not None:
+            r = recs[max(k - 1, 0)]
+            print(k, list(r.grid_corner)[:3], list(r.grid_surf)[:3], r.status_mapping, file=sys.stderr)
+    if pipelined:
+        recs[n - 1] = slam.result(n - 1)
+    wall = time.perf_counter() - t_start if t_start is not None else 0.0
+    est = np.array([np.array(r.pose_map[:]) for r in recs])
+    if maps_out is not None:
+        gc_, gs_ = slam.grids()
+        maps_out["corner"], maps_out["surf"] = gc_.dump(), gs_.dump()
+    slam.close()
+    return est, recs, 1e3 * wall / max(n - 2, 1)
 
 
 def ate(est, truth):
@@ -130,13 +172,29 @@ def ate(est, truth):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=300)
+    ap.add_argument("--mode", choices=["slam", "slam-pipelined", "staged"], default="slam",
+                    help="slam: msfl_slam_add_scan, one synchronisation per scan; slam-pipelined: results fetched one scan late; "
+                         "staged: the round-2 loop of single-stage host-pointer calls")
     args = ap.parse_args()
     world = synth.World(ground_half=45.0)
     truth = trajectory(args.scans)
-    est, ms = run(GpuBackend(0), world, truth, verbose=True)
-    print(json.dumps({"scans": args.scans, "ate_rmse_m": ate(est, truth),
-                      "final_error_m_rad": synth.pose_error(est[-1], truth[-1]),
-                      "latency_ms_per_scan": ms, "note": "single-scan host-pointer calls (includes PCIe staging)"}))
+    if args.mode == "staged":
+        est, ms = run(GpuBackend(0), world, truth, verbose=True)
+        print(json.dumps({"mode": "staged", "scans": args.scans, "ate_rmse_m": ate(est, truth),
+                          "final_error_m_rad": synth.pose_error(est[-1], truth[-1]),
+                          "latency_ms_per_scan": ms, "note": "single-scan host-pointer calls (includes PCIe staging)"}))
+        return
+    scans = [synth.make_scan(world, truth[k], synth.SEED + 5000 + k) for k in range(args.scans)]
+    import gc
+    gc.collect(); gc.disable()
+    est, recs, ms = run_slam(world, truth, pipelined=args.mode == "slam-pipelined", scans=scans)
+    last = recs[-1]
+    print(json.dumps({"mode": args.mode, "scans": args.scans, "ate_rmse_m": ate(est, truth),
+                      "final_error_m_rad": synth.pose_error(est[-1], truth[-1]), "ms_per_scan_end_to_end": ms,
+                      "scans_per_s": 1e3 / ms if ms else None,
+                      "map_points": [last.grid_corner[0], last.grid_surf[0]], "map_cells": [last.grid_corner[1], last.grid_surf[1]],
+                      "mapping_gate_closed_scans": int(sum(1 for r in recs if r.status_mapping != 0)),
+                      "note": "raw host scan in (18 B/pt over PCIe), 480-byte record out; wall clock around the calls"}))
 
 
 if __name__ == "__main__":

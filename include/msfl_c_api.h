@@ -466,6 +466,78 @@ msfl_status msfl_grid_size(msfl_grid* g, int* n_points, int* n_cells);
 /* all points, cells ascending (the reference dumps the map to PLY on shutdown, laser_mapping.cc:95-113) */
 msfl_status msfl_grid_dump(msfl_grid* g, msfl_point* out, int capacity, int* n_out, msfl_mem mem);
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* The per-scan SLAM step, device-resident (BASELINE configs[2]: sequential odometry + mapping).*/
+/*   replaces, for one incoming scan, the chain the reference runs across its two threads:      */
+/*     RealHandleLaserCloudMessage   feature extraction            msf_loam_node.cc:160-378      */
+/*     LaserOdometry::AddLaserScan   MatchScan2Scan + pose chain   laser_odometry.cc:69-95       */
+/*     LaserMapping::Run             TransformAssociateToMap, MatchScan2Map (voxel filters,      */
+/*                                   GetSurroundedCloud x2, gate, scan-to-map), TransformUpdate, */
+/*                                   InsertScan2Map x2             laser_mapping.cc:138-258,260-338 */
+/*   LiDAR-only branch (estimator not initialised: no de-skew, no IMU pre-solve).                */
+/* Raw points in, poses out: every intermediate (features, down-sampled clouds, the surrounded    */
+/* map clouds, their kNN index, the two HybridGrid stores, the pose chain) stays in HBM, all        */
+/* sizes are read by the kernels from device memory, and nothing synchronises with the host        */
+/* between the upload of the scan and the 600-byte result record.  Like the reference's two        */
+/* threads, the odometry chain of scan k+1 (one HIP stream) overlaps the mapping chain of scan k   */
+/* (another stream) when the caller does not wait for every result.                                */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct msfl_slam_s msfl_slam;
+
+typedef struct msfl_slam_config {
+  float  map_resolution;      /* HybridGrid(3.0)                         laser_mapping.cc:44-45 */
+  float  leaf_corner;         /* downsize_filter_corner_ 0.2             :60-63 */
+  float  leaf_surf;           /* downsize_filter_surf_   0.4             :64-68 */
+  int    min_map_corner;      /* MatchScan2Map runs iff corner > 10 ...  :284 */
+  int    min_map_surf;        /* ... && surf > 50                        :285 */
+  int    max_scan_points;     /* largest scan add_scan will see (capacity of the device buffers), e.g. 28 800 for a VLP-16 */
+  int    max_rings;           /* rings of the sensor (16 / 64 / 128): bounds the per-scan sharp / flat counts the launches are sized for */
+  double pose_odom2map[7];    /* initial pose_odom2map_ (identity in the reference, laser_mapping.h:88) */
+} msfl_slam_config;
+
+typedef struct msfl_slam_result {
+  double pose_odom[7];        /* pose_scan2world_ of the odometry thread (laser_odometry.cc:79), odometry frame */
+  double pose_map[7];         /* pose_map_scan2world_ after MatchScan2Map (laser_mapping.cc:304-311): the SLAM output */
+  double pose_curr2last[7];   /* pose_curr2last_ (laser_odometry.cc:75) */
+  double pose_odom2map[7];    /* pose_odom2map_ after TransformUpdate (laser_mapping.h:59-61) */
+  msfl_match_info odometry;   /* MatchScan2Scan diagnostics (status MSFL_TOO_FEW_CORRESPONDENCES where the reference returns false) */
+  msfl_match_info mapping;    /* MatchScan2Map diagnostics (all zero when the gate was closed) */
+  int scan_index;             /* 0-based count of add_scan calls */
+  int status_extract;         /* msfl_status of the extraction (MSFL_BAD_RING, MSFL_CAPACITY, ...) */
+  int status_mapping;         /* 0, or MSFL_MAP_TOO_SMALL when the gate (:284-285) kept MatchScan2Map from running,
+                                 or MSFL_CAPACITY when a list did not fit the on-chip voxel filter */
+  int n_full, n_sharp, n_less_sharp, n_flat, n_less_flat;   /* extraction counts */
+  int n_corner_ds, n_surf_ds;           /* after the 0.2 / 0.4 m voxel filters (:264-270) */
+  int n_map_corner, n_map_surf;         /* GetSurroundedCloud sizes (:273-278) */
+  int grid_corner[8], grid_surf[8];     /* map store after the inserts: {points, cells, pool_top, dropped, overflow, cells touched, ...} */
+} msfl_slam_result;
+
+void msfl_slam_default_config(msfl_slam_config* c);
+
+/* One SLAM pipeline = the reference's LaserOdometry + LaserMapping pair (two streams, two matchers' scratch, two map stores). */
+msfl_status msfl_slam_create(const msfl_params* params, const msfl_slam_config* config, int device, msfl_slam** out);
+void msfl_slam_destroy(msfl_slam* s);
+
+/* Feed one scan as pcl::fromROSMsg delivers it (driver order, `n` points + ring ids).  With mem == MSFL_MEM_HOST the
+   arrays are copied into pinned staging before the call returns; with MSFL_MEM_DEVICE they must stay untouched until
+   this scan's result is out.
+     result != NULL : wait for this scan's mapping result and deliver it (one synchronisation per scan);
+     result == NULL : enqueue only; fetch the record later with msfl_slam_get_result.  At most two scans are in flight:
+                      the call first waits for scan index-2 (almost always long done).
+   Returns a status for argument / HIP errors only; per-scan outcomes are in the record. */
+msfl_status msfl_slam_add_scan(msfl_slam* s, const msfl_point* pts, const uint16_t* ring, int n, msfl_mem mem,
+                               msfl_slam_result* result);
+
+/* Wait for the scan with the given index (one of the last four fed) and deliver its record. */
+msfl_status msfl_slam_get_result(msfl_slam* s, int scan_index, msfl_slam_result* result);
+
+/* The two map stores (hybrid_grid_map_corner_ / hybrid_grid_map_surf_), e.g. for msfl_grid_dump at shutdown
+   (laser_mapping.cc:95-113).  Owned by the pipeline; do not destroy.  Waits for everything in flight. */
+msfl_status msfl_slam_grids(msfl_slam* s, msfl_grid** corner, msfl_grid** surf);
+const char* msfl_slam_last_error(const msfl_slam* s);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -26,6 +26,8 @@ EXPORTED = [
     "msfl_transform_cloud",
     "msfl_delta_qp", "msfl_deskew_cloud", "msfl_undistort_cloud",
     "msfl_grid_create", "msfl_grid_destroy", "msfl_grid_insert_scan", "msfl_grid_get_surrounded", "msfl_grid_size", "msfl_grid_dump",
+    "msfl_slam_default_config", "msfl_slam_create", "msfl_slam_destroy", "msfl_slam_add_scan", "msfl_slam_get_result", "msfl_slam_grids",
+    "msfl_slam_last_error",
 ]
 
 
@@ -100,6 +102,21 @@ class FeaturesBatch(C.Structure):
                 ("flat_idx", C.c_void_p), ("less_flat_idx", C.c_void_p),
                 ("n_full", C.c_void_p), ("n_sharp", C.c_void_p), ("n_less_sharp", C.c_void_p),
                 ("n_flat", C.c_void_p), ("n_less_flat", C.c_void_p)]
+
+
+class SlamConfig(C.Structure):
+    _fields_ = [("map_resolution", C.c_float), ("leaf_corner", C.c_float), ("leaf_surf", C.c_float),
+                ("min_map_corner", C.c_int), ("min_map_surf", C.c_int), ("max_scan_points", C.c_int), ("max_rings", C.c_int),
+                ("pose_odom2map", C.c_double * 7)]
+
+
+class SlamResult(C.Structure):
+    _fields_ = [("pose_odom", C.c_double * 7), ("pose_map", C.c_double * 7), ("pose_curr2last", C.c_double * 7),
+                ("pose_odom2map", C.c_double * 7), ("odometry", MatchInfo), ("mapping", MatchInfo),
+                ("scan_index", C.c_int), ("status_extract", C.c_int), ("status_mapping", C.c_int),
+                ("n_full", C.c_int), ("n_sharp", C.c_int), ("n_less_sharp", C.c_int), ("n_flat", C.c_int), ("n_less_flat", C.c_int),
+                ("n_corner_ds", C.c_int), ("n_surf_ds", C.c_int), ("n_map_corner", C.c_int), ("n_map_surf", C.c_int),
+                ("grid_corner", C.c_int * 8), ("grid_surf", C.c_int * 8)]
 
 
 class MsflError(RuntimeError):
@@ -499,3 +516,88 @@ class Grid:
         n_out = C.c_int(0)
         self.handle._check(self.lib.msfl_grid_dump(self.g, _vp(out), C.c_int(cap), C.byref(n_out), C.c_int(MEM_HOST)), "msfl_grid_dump")
         return out[:n_out.value].copy()
+
+
+class _BorrowedGrid(Grid):
+    """A map store owned by a Slam pipeline (never destroyed from here)."""
+
+    def __init__(self, lib, g, err):
+        self.lib, self.g, self._err = lib, g, err
+        self.handle = self
+
+    def _check(self, status, what, allow=()):
+        if status != OK and status not in allow:
+            raise MsflError(status, what, self._err())
+        return status
+
+    def close(self):
+        self.g = C.c_void_p()
+
+
+class Slam:
+    """Device-resident per-scan SLAM step (msfl_slam_*): raw scan in, poses out, everything in between stays in HBM."""
+
+    def __init__(self, device=0, max_scan_points=28800, max_rings=16, pose_odom2map=None, params=None, **cfg):
+        self.lib = load()
+        self.lib.msfl_slam_last_error.restype = C.c_char_p
+        self.lib.msfl_slam_last_error.argtypes = [C.c_void_p]
+        c = SlamConfig()
+        self.lib.msfl_slam_default_config(C.byref(c))
+        c.max_scan_points, c.max_rings = int(max_scan_points), int(max_rings)
+        if pose_odom2map is not None:
+            for k in range(7):
+                c.pose_odom2map[k] = float(pose_odom2map[k])
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        self.s = C.c_void_p()
+        st = self.lib.msfl_slam_create(C.byref(params) if params is not None else None, C.byref(c), C.c_int(device), C.byref(self.s))
+        if st != OK:
+            raise MsflError(st, "msfl_slam_create", "no GPU / HIP runtime available (there is no CPU fallback)" if st == HIP_ERROR else "")
+        self.n_scans = 0
+
+    def _err(self):
+        return (self.lib.msfl_slam_last_error(self.s) or b"").decode()
+
+    def close(self):
+        if self.s:
+            self.lib.msfl_slam_destroy(self.s)
+            self.s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_scan(self, pts, ring, wait=True):
+        """Feed one scan (host arrays).  wait=True: returns this scan's SlamResult; False: enqueue only."""
+        pts = _pts(pts)
+        ring = np.ascontiguousarray(ring, dtype=np.uint16)
+        r = SlamResult() if wait else None
+        st = self.lib.msfl_slam_add_scan(self.s, _vp(pts), _vp(ring), C.c_int(len(pts)), C.c_int(MEM_HOST), C.byref(r) if wait else None)
+        if st != OK:
+            raise MsflError(st, "msfl_slam_add_scan", self._err())
+        self.n_scans += 1
+        return r
+
+    def add_scan_device(self, pts_ptr, ring_ptr, n, wait=True):
+        r = SlamResult() if wait else None
+        st = self.lib.msfl_slam_add_scan(self.s, _vp(pts_ptr), _vp(ring_ptr), C.c_int(int(n)), C.c_int(MEM_DEVICE), C.byref(r) if wait else None)
+        if st != OK:
+            raise MsflError(st, "msfl_slam_add_scan(device)", self._err())
+        self.n_scans += 1
+        return r
+
+    def result(self, scan_index):
+        r = SlamResult()
+        st = self.lib.msfl_slam_get_result(self.s, C.c_int(int(scan_index)), C.byref(r))
+        if st != OK:
+            raise MsflError(st, "msfl_slam_get_result", self._err())
+        return r
+
+    def grids(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        st = self.lib.msfl_slam_grids(self.s, C.byref(a), C.byref(b))
+        if st != OK:
+            raise MsflError(st, "msfl_slam_grids", self._err())
+        return _BorrowedGrid(self.lib, a, self._err), _BorrowedGrid(self.lib, b, self._err)

@@ -223,7 +223,7 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // descriptor is computed and kept on the device; the dense cell table has a fixed capacity
 // (default 4 M cells, MSFL_GRID_CAP_CELLS) and the device grows the cell edge if the map's bounding
 // box would need more (larger cells stay exact).
-msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) {
+msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi, const int* n_dev = nullptr) {
   ScopedTimer timer(h, T_INDEX);
   mi.n_input = n;
   hipStream_t st = h->stream;
@@ -258,7 +258,7 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   }
   if (n > 0) {
     const int blocks = std::min(div_up(n, 1024), 256);   // 6 atomics per workgroup, all on one line: four points per lane and pass
-    hipLaunchKernelGGL(grid_bbox_kernel, dim3(blocks), dim3(256), 0, st, pts, n, mi.bbox.as<int>());
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(blocks), dim3(256), 0, st, pts, n, mi.bbox.as<int>(), n_dev);
   }
   const double radius = std::sqrt((double)h->prm.map_knn_max_sq_dist);
   if (n == 0)
@@ -273,7 +273,7 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   if (span > zeroed) HIPCHK(h, hipMemsetAsync(h->idx_count.p, 0, span * sizeof(int), st));
   if (n > 0)
     hipLaunchKernelGGL(grid_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, (const int*)mi.bbox.as<int>(), radius, cap,
-                       mi.gdesc.as<GridDesc>(), h->idx_cell_of.as<int>(), h->idx_count.as<int>());
+                       mi.gdesc.as<GridDesc>(), h->idx_cell_of.as<int>(), h->idx_count.as<int>(), n_dev);
   size_t tmp_bytes = 0;
   HIPCHK(h, rocprim::exclusive_scan(nullptr, tmp_bytes, h->idx_count.as<int>(), mi.cell_start.as<int>(), 0, (size_t)((int)span), rocprim::plus<int>(), st));
   HIPCHK(h, h->idx_cub.reserve(tmp_bytes));
@@ -281,7 +281,7 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi) 
   if (n > 0)
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, pts, n, h->idx_cell_of.as<int>(),
                        mi.cell_start.as<int>(), h->idx_count.as<int>(), mi.sorted.as<float4>(), mi.pos_of.as<int>(),
-                       mi.gdesc.as<GridDesc>(), mi.bbox.as<int>());
+                       mi.gdesc.as<GridDesc>(), mi.bbox.as<int>(), n_dev);
   HIPCHK(h, hipGetLastError());
   h->idx_count_zero = std::max(zeroed, span);
   if (!mi.want_pending) {
@@ -857,3 +857,4 @@ msfl_status msfl_solve_records(msfl_handle* h, const msfl_point* corner, int n_c
 #include "msfl_api_stage_ab.inc"
 #include "msfl_api_grid.inc"
 #include "msfl_api_deskew.inc"
+#include "msfl_api_slam.inc"

@@ -908,13 +908,25 @@ __global__ void __launch_bounds__(256) voxel_batch_run_centroid_kernel(VoxelBatc
 constexpr int kVoxMaxPoints = 65535;                // the first point of a run is a 16-bit number
 constexpr int kVoxSmallPoints = 4096;
 
-template <int kVoxWaves, int kVoxRunsPerWave>
+// kGlobal (third instantiation, <16, 4096, true>): the run records and the two order buffers live in a global scratch
+// area (per cloud kVoxMaxRuns x 8 B + 2 x kVoxMaxRuns x 2 B, L2-resident, same code) instead of LDS.  65 536 run slots,
+// 4 096 per wavefront slice, can never overflow (a slice holds at most 4 096 points), so a cloud of up to 65 535 points
+// that the LDS forms refused for its RUN count (flag 4) is served without leaving the device: the per-scan SLAM step has
+// no host round trip in which it could fall back to the device-wide form.  only_escalated == 2: serve flag-4 clouds.
+template <int kVoxWaves, int kVoxRunsPerWave, bool kGlobal = false>
 __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBatchView v, float4* __restrict__ staging, float4* __restrict__ run_sums,
-                                                                          int* __restrict__ m_out, int* __restrict__ flags, int only_escalated) {
+                                                                          int* __restrict__ m_out, int* __restrict__ flags, int only_escalated,
+                                                                          unsigned long long* __restrict__ g_run = nullptr,
+                                                                          unsigned short* __restrict__ g_ord = nullptr) {
   constexpr int kVoxMaxRuns = kVoxWaves * kVoxRunsPerWave;
   constexpr int kThreads = 64 * kVoxWaves;
-  __shared__ unsigned long long s_run[kVoxMaxRuns];           // [coords 3 x 14 bits, later the voxel index : 42][first point : 16][length - 1 : 6]
-  __shared__ unsigned short s_ord[2][kVoxMaxRuns];
+  constexpr int kLdsRuns = kGlobal ? 1 : kVoxMaxRuns;
+  __shared__ unsigned long long s_run_lds[kLdsRuns];          // [coords 3 x 14 bits, later the voxel index : 42][first point : 16][length - 1 : 6]
+  __shared__ unsigned short s_ord_lds[2][kLdsRuns];
+  unsigned long long* const s_run = kGlobal ? g_run + (size_t)blockIdx.x * kVoxMaxRuns : s_run_lds;
+  unsigned short* const s_ord0 = kGlobal ? g_ord + (size_t)blockIdx.x * 2 * kVoxMaxRuns : s_ord_lds[0];
+  unsigned short* const s_ord1 = kGlobal ? g_ord + (size_t)blockIdx.x * 2 * kVoxMaxRuns + kVoxMaxRuns : s_ord_lds[1];
+  auto s_ord = [&](int which) __attribute__((always_inline)) { return which ? s_ord1 : s_ord0; };
   __shared__ unsigned short s_hist[kVoxWaves][256];
   __shared__ int s_wcount[kVoxWaves];
   __shared__ int s_bb[6];
@@ -925,7 +937,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   const int n = v.count ? min(max(v.count[b], 0), cap) : cap;
   // the small instantiation runs first and ESCALATES (flag 5) what it cannot hold; the large one then only serves those
   constexpr bool kSmall = kVoxWaves < 16;
-  if (only_escalated && flags[b] != 5) return;
+  if (only_escalated && flags[b] != (only_escalated == 2 ? 4 : 5)) return;
   if (tid == 0) { s_flag = 0; for (int a = 0; a < 3; a++) { s_bb[a] = INT32_MAX; s_bb[3 + a] = INT32_MIN; } }
   __syncthreads();
   if (n > (kSmall ? kVoxSmallPoints : kVoxMaxPoints)) { if (tid == 0) { flags[b] = kSmall ? 5 : 4; m_out[b] = 0; } return; }
@@ -1037,7 +1049,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
                     i2 = (long long)((int)(r >> 22) & 0x3fff) - 8192 - mb2;
     const unsigned long long cell = (unsigned long long)(i0 + i1 * d0 + i2 * d0 * d1);
     s_run[id] = (cell << 22) | (r & 0x3fffffull);
-    s_ord[0][wbase + e] = (unsigned short)id;              // run ids in arrival order
+    s_ord(0)[wbase + e] = (unsigned short)id;              // run ids in arrival order
   }
   int nbits = 1;
   while ((1ll << nbits) < cells) nbits++;
@@ -1052,7 +1064,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
     for (int base = e0; base < e1; base += 64) {
       const int pos = base + lane;
       const bool valid = pos < e1;
-      const unsigned dg = valid ? (unsigned)((s_run[s_ord[cur][pos]] >> (22 + shift)) & 0xffu) : 0x100u;
+      const unsigned dg = valid ? (unsigned)((s_run[s_ord(cur)[pos]] >> (22 + shift)) & 0xffu) : 0x100u;
       unsigned long long peers = __ballot(valid);
 #pragma unroll
       for (int bit = 0; bit < 8; bit++) { const unsigned long long m = __ballot((dg >> bit) & 1u); peers &= ((dg >> bit) & 1u) ? m : ~m; }
@@ -1078,7 +1090,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
     for (int base = e0; base < e1; base += 64) {
       const int pos = base + lane;
       const bool valid = pos < e1;
-      const unsigned short id = valid ? s_ord[cur][pos] : (unsigned short)0;
+      const unsigned short id = valid ? s_ord(cur)[pos] : (unsigned short)0;
       const unsigned dg = valid ? (unsigned)((s_run[id] >> (22 + shift)) & 0xffu) : 0x100u;
       unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -1086,7 +1098,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
       if (valid) {
         const int rank = __popcll(peers & ((1ull << lane) - 1ull));
         const int at = s_hist[wave][dg];
-        s_ord[cur ^ 1][at + rank] = id;
+        s_ord(cur ^ 1)[at + rank] = id;
         if (rank == 0) s_hist[wave][dg] = (unsigned short)(at + __popcll(peers));
       }
     }
@@ -1094,13 +1106,13 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
     __syncthreads();
   }
   // ---- phase 4: voxel heads (positions in the sorted order) into the other order buffer ----
-  unsigned short* heads_at = s_ord[cur ^ 1];
+  unsigned short* heads_at = s_ord(cur ^ 1);
   if (tid == 0) s_total = 0;
   __syncthreads();
   for (int base = 0; base < E; base += kThreads) {
     const int pos = base + tid;
     bool head = false;
-    if (pos < E) head = pos == 0 || (s_run[s_ord[cur][pos]] >> 22) != (s_run[s_ord[cur][pos - 1]] >> 22);
+    if (pos < E) head = pos == 0 || (s_run[s_ord(cur)[pos]] >> 22) != (s_run[s_ord(cur)[pos - 1]] >> 22);
     const unsigned long long hm = __ballot(head);
     if (lane == 0) s_wsum[wave] = __popcll(hm);
     __syncthreads();
@@ -1139,7 +1151,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
       for (int i = 0; i < 4; i++) { const int kk = k + min(e + i, len - 1); src[i] = v.idx ? v.idx[cloud_o + kk] : kk; }
     };
     for (int j = j0 + 1; j < j1; j++) {
-      const unsigned long long rec = s_run[s_ord[cur][j]];
+      const unsigned long long rec = s_run[s_ord(cur)[j]];
       const int k = (int)((rec >> 6) & 0xffffu), len = (int)(rec & 0x3fu) + 1;
       total += len;
       int src[4];
@@ -1159,7 +1171,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   // neighbour's chain of dependent point loads five voxels in a row
   for (int r = tid; r < m; r += kThreads) {
     const int j0 = heads_at[r], j1 = (r + 1 < m) ? (int)heads_at[r + 1] : E;
-    const int id0 = s_ord[cur][j0];
+    const int id0 = s_ord(cur)[j0];
     const float4 first = sum_of(id0);
     const int len0 = (int)(s_run[id0] & 0x3fu) + 1;
     float sx = first.x, sy = first.y, sz = first.z, st = first.w;
@@ -1178,10 +1190,10 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   for (int q = tid; q < n_multi; q += kThreads) {
     const int r = multi_list[q];
     const int j0 = heads_at[r], j1 = (r + 1 < m) ? (int)heads_at[r + 1] : E;
-    const int id0 = s_ord[cur][j0];
+    const int id0 = s_ord(cur)[j0];
     const int len0 = (int)(s_run[id0] & 0x3fu) + 1;
     int later = 0;
-    for (int j = j0 + 1; j < j1; j++) later += (int)(s_run[s_ord[cur][j]] & 0x3fu) + 1;
+    for (int j = j0 + 1; j < j1; j++) later += (int)(s_run[s_ord(cur)[j]] & 0x3fu) + 1;
     if (later > kBigVoxel) {
       const int at = atomicAdd(&s_nbig, 1);
       if (at < kBigCap) { big_list[at] = (unsigned short)r; continue; }
@@ -1196,18 +1208,18 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   for (int q = wave; q < n_big; q += kVoxWaves) {
     const int r = big_list[q];
     const int j0 = heads_at[r], j1 = (r + 1 < m) ? (int)heads_at[r + 1] : E;     // j1 - j0 >= 2 here
-    const int id0 = s_ord[cur][j0];
+    const int id0 = s_ord(cur)[j0];
     const float4 first = sum_of(id0);
     float sx = first.x, sy = first.y, sz = first.z, st = first.w;
     int total = (int)(s_run[id0] & 0x3fu) + 1;
     // software pipeline over the runs: the next run's points are loading while this one is summed
-    unsigned long long rec = s_run[s_ord[cur][j0 + 1]];
+    unsigned long long rec = s_run[s_ord(cur)[j0 + 1]];
     int k = (int)((rec >> 6) & 0xffffu), len = (int)(rec & 0x3fu) + 1;
     float4 p = vb_point(v, b, k + min(lane, len - 1));
     for (int j = j0 + 1; j < j1; j++) {
       const float4 pc = p; const int lc = len;
       if (j + 1 < j1) {
-        rec = s_run[s_ord[cur][j + 1]];
+        rec = s_run[s_ord(cur)[j + 1]];
         k = (int)((rec >> 6) & 0xffffu); len = (int)(rec & 0x3fu) + 1;
         p = vb_point(v, b, k + min(lane, len - 1));
       }

@@ -58,8 +58,11 @@ __host__ __device__ __forceinline__ float ordered_to_float(int i) {
 }
 
 // bbox[0..2] = min (ordered ints), bbox[3..5] = max; pre-initialised to INT_MAX / INT_MIN
-__global__ void __launch_bounds__(256) grid_bbox_kernel(const float4* __restrict__ pts, int n, int* __restrict__ bbox) {
+// n_dev (optional): the number of valid points lives on the device (a surrounded cloud that never visits the host);
+// `n` is then the launch's upper bound
+__global__ void __launch_bounds__(256) grid_bbox_kernel(const float4* __restrict__ pts, int n, int* __restrict__ bbox, const int* __restrict__ n_dev = nullptr) {
   __shared__ float s_mn[4][3], s_mx[4][3];
+  if (n_dev) n = min(n, max(*n_dev, 0));
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   auto take = [&](float4 p) {
     if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
@@ -165,8 +168,9 @@ __global__ void grid_setup_kernel(int* __restrict__ bbox, double radius, int cap
 // per build than a separate one-thread setup kernel; workgroup 0 publishes it.
 __global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restrict__ pts, int n, const int* __restrict__ bbox,
                                                           double radius, int cap_cells, GridDesc* __restrict__ gout,
-                                                          int* __restrict__ cell_of, int* __restrict__ count) {
+                                                          int* __restrict__ cell_of, int* __restrict__ count, const int* __restrict__ n_dev = nullptr) {
   __shared__ GridDesc s_g;
+  if (n_dev) n = min(n, max(*n_dev, 0));
   if (threadIdx.x == 0) {
     s_g = grid_desc_from_bbox(bbox, radius, cap_cells);
     if (blockIdx.x == 0) *gout = s_g;
@@ -194,8 +198,9 @@ __global__ void __launch_bounds__(256) grid_scatter_kernel(const float4* __restr
                                                             const int* __restrict__ cell_of,
                                                             const int* __restrict__ cell_start, int* __restrict__ cursor,
                                                             float4* __restrict__ sorted, int* __restrict__ pos_of,
-                                                            GridDesc* __restrict__ g, int* __restrict__ bbox) {
+                                                            GridDesc* __restrict__ g, int* __restrict__ bbox, const int* __restrict__ n_dev = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) n = min(n, max(*n_dev, 0));
   if (i == 0) { g->n_pts = cell_start[g->n_cells]; grid_bbox_rearm(bbox); }     // number of indexed (finite) points; bbox ready for the next build
   if (i >= n) return;
   const int c = cell_of[i];
@@ -422,7 +427,12 @@ struct BatchView {
   int rec_begin = 0;        // association kernels: first record of this launch (a host-buffer batch is associated chunk by chunk as it arrives)
   int c0, s0;               // corner_off[0], surf_off[0] (host copies)
   int n_surf_total;         // surf_off[n_scans] - surf_off[0]
+  int dyn = 0;              // 1: the offsets were written on the device (per-scan SLAM step); n_records is then an upper bound and the
+                            // record count is rec_off[n_scans]; c0 = s0 = 0 and n_surf_total is the surf cloud's CAPACITY (a layout constant)
 };
+__device__ __forceinline__ int batch_records(const BatchView& bv) {
+  return bv.dyn ? min(bv.n_records, bv.rec_off[bv.n_scans]) : bv.n_records;
+}
 
 // scan owning global record index g (upper bound - 1 over rec_off)
 __device__ __forceinline__ int find_scan(const int* __restrict__ rec_off, int n_scans, int g);
@@ -475,7 +485,7 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
                      const int* __restrict__ pos_c, const int* __restrict__ pos_s,
                      float max_sq_dist, DeskewView dv, int* __restrict__ nn, unsigned long long* __restrict__ n_candidates = nullptr) {
   const int g = bv.rec_begin + blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= bv.n_records) return;
+  if (g >= batch_records(bv)) return;
   const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);
   int* out = nn + 5 * (size_t)g;
   if (status[b] != 0) { out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1; return; }
@@ -540,7 +550,7 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
                     const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
                     double* __restrict__ rec, double* __restrict__ full) {
   const int g = bv.rec_begin + blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= bv.n_records) return;
+  if (g >= batch_records(bv)) return;
   const int* in = nn + 5 * (size_t)g;
   const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);
   const int local = g - bv.rec_off[b];
@@ -581,7 +591,7 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
 // {C, N} x n_records (host/debug format) -> compact internal records
 __global__ void __launch_bounds__(256) pack_records_kernel(BatchView bv, const double* __restrict__ full, double* __restrict__ rec) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= bv.n_records) return;
+  if (g >= batch_records(bv)) return;
   const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);
   const int local = g - bv.rec_off[b];
   const int nc = bv.corner_off[b + 1] - bv.corner_off[b];

@@ -1,0 +1,104 @@
+// msfl_slam.cuh — glue kernels of the device-resident per-scan SLAM step (msfl_api_slam.inc).
+//
+// The stages themselves are the kernels of stage A / B / C, the voxel filter and the map store; what lives here is
+// what the reference does in host code BETWEEN them (laser_odometry.cc:69-95, laser_mapping.cc:138-258,260-338) and
+// therefore used to cost a PCIe round trip each: the feature clouds gathered out of the full cloud, the pose chain
+// (Rigid3d operator* / inverse, rigid_transform.h:105-111), the map gate (laser_mapping.cc:284-285), the offset
+// tables of the two matchers, and the result record.  Every size is read from device memory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "msfl_math.cuh"
+#include "msfl_grid.cuh"
+
+namespace msfl {
+
+// counts block of one scan, written by the extraction kernels: [n_full, n_sharp, n_less_sharp, n_flat, n_less_flat, status, -, -]
+enum { SC_FULL = 0, SC_SHARP, SC_LESS_SHARP, SC_FLAT, SC_LESS_FLAT, SC_STATUS, SC_OVERFLOW, SC_WORDS = 8 };
+
+struct SlamCaps { int sharp, less_sharp, flat, less_flat; };     // host-side bounds the launches are sized for
+
+// The four feature clouds of TimestampedPointCloud (timestamped_pointcloud.h:11-42) as contiguous arrays: the reference
+// push_back()s copies (msf_loam_node.cc:279-344); here one gather out of cloud_full_res per list.  Also writes the five
+// offset pairs of the scan-to-scan matcher for THIS scan as `curr` against `last` (the previous scan's counts):
+//   odo_off = [0, last_ls | 0, last_lf | 0, sharp | 0, flat | 0, sharp + flat]
+__global__ void __launch_bounds__(256)
+slam_gather_kernel(const float4* __restrict__ full, const uint16_t* __restrict__ ring, const int* __restrict__ sharp_idx,
+                   const int* __restrict__ ls_idx, const int* __restrict__ flat_idx, const int* __restrict__ lf_idx, int* __restrict__ cnt,
+                   SlamCaps caps, float4* __restrict__ sharp_pts, float4* __restrict__ ls_pts, uint16_t* __restrict__ ls_ring,
+                   float4* __restrict__ flat_pts, float4* __restrict__ lf_pts, uint16_t* __restrict__ lf_ring,
+                   const int* __restrict__ last_cnt, SlamCaps last_caps, int* __restrict__ odo_off) {
+  const int list = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ok = cnt[SC_STATUS] == 0;
+  const int n_sharp = ok ? min(cnt[SC_SHARP], caps.sharp) : 0, n_ls = ok ? min(cnt[SC_LESS_SHARP], caps.less_sharp) : 0;
+  const int n_flat = ok ? min(cnt[SC_FLAT], caps.flat) : 0, n_lf = ok ? min(cnt[SC_LESS_FLAT], caps.less_flat) : 0;
+  if (list == 0 && i == 0) {
+    const bool lok = last_cnt && last_cnt[SC_STATUS] == 0;
+    odo_off[0] = 0; odo_off[1] = lok ? min(last_cnt[SC_LESS_SHARP], last_caps.less_sharp) : 0;
+    odo_off[2] = 0; odo_off[3] = lok ? min(last_cnt[SC_LESS_FLAT], last_caps.less_flat) : 0;
+    odo_off[4] = 0; odo_off[5] = n_sharp;
+    odo_off[6] = 0; odo_off[7] = n_flat;
+    odo_off[8] = 0; odo_off[9] = n_sharp + n_flat;
+    // a list longer than the launch bound (a ring id beyond the configured ring count): reported, the scan is not matched
+    cnt[SC_OVERFLOW] = ok && (cnt[SC_SHARP] > caps.sharp || cnt[SC_LESS_SHARP] > caps.less_sharp || cnt[SC_FLAT] > caps.flat ||
+                              cnt[SC_LESS_FLAT] > caps.less_flat) ? 1 : 0;
+  }
+  if (list == 0) { if (i < n_sharp) sharp_pts[i] = full[sharp_idx[i]]; }
+  else if (list == 1) { if (i < n_ls) { const int j = ls_idx[i]; ls_pts[i] = full[j]; ls_ring[i] = ring[j]; } }
+  else if (list == 2) { if (i < n_flat) flat_pts[i] = full[flat_idx[i]]; }
+  else { if (i < n_lf) { const int j = lf_idx[i]; lf_pts[i] = full[j]; lf_ring[i] = ring[j]; } }
+}
+
+// Rigid3d operator* (rigid_transform.h:105-111) and inverse() (:66-70)
+__device__ __forceinline__ pose7 pose_compose(const pose7& a, const pose7& b) {
+  pose7 o;
+  o.t = quat_rotate(a.q, b.t) + a.t;
+  o.q = quat_normalized(quat_mul(a.q, b.q));
+  return o;
+}
+__device__ __forceinline__ pose7 pose_inverse(const pose7& a) {
+  pose7 o;
+  o.q.x = -a.q.x; o.q.y = -a.q.y; o.q.z = -a.q.z; o.q.w = a.q.w;
+  const d3 r = quat_rotate(o.q, a.t);
+  o.t = mk3(-r.x, -r.y, -r.z);
+  return o;
+}
+
+// odometry thread, after MatchScan2Scan: pose_scan2world_ = pose_scan2world_ * pose_curr2last_ (laser_odometry.cc:79;
+// not on the first scan, :72-73), and the copy the mapping thread receives as odom_result.odom_pose (:84-85).
+// A scan whose extraction failed leaves the chain untouched.
+__global__ void slam_odom_pose_kernel(const double* __restrict__ c2l, double* __restrict__ odo_cur, double* __restrict__ pose_odom_k,
+                                      double* __restrict__ c2l_k, const int* __restrict__ cnt, int first) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  pose7 odo = load_pose(odo_cur);
+  if (!first && cnt[SC_STATUS] == 0 && cnt[SC_OVERFLOW] == 0) { odo = pose_compose(odo, load_pose(c2l)); store_pose(odo_cur, odo); }
+  store_pose(pose_odom_k, odo);
+  for (int k = 0; k < 7; k++) c2l_k[k] = c2l[k];
+}
+
+// mapping thread: mode 0 = TransformAssociateToMap (laser_mapping.h:55-57), mode 1 = TransformUpdate (:59-61)
+__global__ void slam_map_pose_kernel(double* __restrict__ odom2map, const double* __restrict__ pose_odom_k, double* __restrict__ pose_map_k, int mode) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (mode == 0) store_pose(pose_map_k, pose_compose(load_pose(odom2map), load_pose(pose_odom_k)));
+  else store_pose(odom2map, pose_compose(load_pose(pose_map_k), pose_inverse(load_pose(pose_odom_k))));
+}
+
+// Between GetSurroundedCloud and MatchScan2Map (laser_mapping.cc:279-311): the gate `corner > 10 && surf > 50`, the
+// matcher's offset tables [0, m_c | 0, m_s | 0, m_c + m_s] and its status word (non-zero = the kernels skip the scan and
+// the pose guess passes through, exactly the reference's else-branch).
+__global__ void slam_map_gate_kernel(const int* __restrict__ n_map_c, const int* __restrict__ n_map_s, int min_c, int min_s,
+                                     const int* __restrict__ m_c, const int* __restrict__ m_s, const int* __restrict__ vflag_c,
+                                     const int* __restrict__ vflag_s, const int* __restrict__ cnt, int* __restrict__ in_off,
+                                     int* __restrict__ status) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int mc = max(*m_c, 0), ms = max(*m_s, 0);
+  in_off[0] = 0; in_off[1] = mc; in_off[2] = 0; in_off[3] = ms; in_off[4] = 0; in_off[5] = mc + ms;
+  int s = 0;
+  if (cnt[SC_STATUS] != 0 || cnt[SC_OVERFLOW] != 0) s = 3;                       // MSFL_BAD_ARG: nothing to match
+  else if (*vflag_c != 0 || *vflag_s != 0) s = 7;                                // MSFL_CAPACITY: a list did not fit the on-chip filter
+  else if (!(*n_map_c > min_c && *n_map_s > min_s)) s = 2;                       // MSFL_MAP_TOO_SMALL: the gate
+  *status = s;
+}
+
+}  // namespace msfl

@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_cuda_first():
+    """torch refuses to initialise its HIP context after another library has touched the runtime in-process: whatever order
+    the GPU tests run in, torch (when a GPU is there) goes first."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda:0")
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure), built on demand from oracle/msfl_oracle.c."""

@@ -38,6 +38,21 @@ class OracleBackend:
         return self.o.HybridGrid(3.0, 0.2), self.o.HybridGrid(3.0, 0.4)
 
 
+class OracleBackendRigid3d(OracleBackend):
+    """The oracle-driven loop with the reference's own Rigid3d algebra (rigid_transform.h:78-82,105-111,131-137) instead of
+    the example's numpy matrices: what the device-resident SLAM step is compared with."""
+
+    def compose(self, a, b):
+        return self.o.pose_compose(a, b)
+
+    def inverse(self, a):
+        qc = np.r_[-np.asarray(a[3:6]), a[6]]
+        return np.r_[-self.o.quat_rotate(qc, np.asarray(a[:3], np.float64)), qc]
+
+    def transform(self, pose, pts):
+        return self.o.transform_cloud(pts, pose)
+
+
 def test_replay_matches_oracle_pipeline(oracle):
     world = synth.World(ground_half=45.0)
     truth = rp.trajectory(24)
@@ -49,6 +64,48 @@ def test_replay_matches_oracle_pipeline(oracle):
     # and the SLAM loop actually tracks: bounded absolute error against ground truth
     assert rp.ate(est_g, truth) < 0.3       # cold start: the first scans only have odometry, the map is still empty
     assert all(v < 100.0 for v in ms.values()), ms        # the reference's 100 ms real-time budget per stage
+
+
+def _oracle_loop(oracle, world, truth, n):
+    """rp.run with the oracle backend on the first n poses, cached per session (the 300-scan loop takes ~20 s)."""
+    key = n
+    if key not in _oracle_loop.cache:
+        maps = {}
+        _oracle_loop.cache[key] = (rp.run(OracleBackendRigid3d(oracle), world, truth[:n], maps_out=maps)[0], maps)
+    return _oracle_loop.cache[key]
+
+
+_oracle_loop.cache = {}
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_device_resident_slam_step_matches_the_oracle_loop_over_300_scans(oracle, pipelined):
+    """BASELINE configs[2] through msfl_slam_add_scan (raw scan in, pose out, nothing but the scan and the record crosses
+    PCIe): every one of 300 poses within 1e-6 m / 1e-6 rad of the oracle-driven loop, the same ATE, and the two map
+    stores equal to the oracle's at the end.  Pipelined = results fetched one scan late, so that the odometry chain of
+    scan k + 1 overlaps the mapping chain of scan k on the second stream; it must give the same poses bit for bit."""
+    n = 300
+    world = synth.World(ground_half=45.0)
+    truth = rp.trajectory(n)
+    est_o, maps_o = _oracle_loop(oracle, world, truth, n)
+    maps_g = {}
+    est_g, recs, ms = rp.run_slam(world, truth, pipelined=pipelined, maps_out=maps_g)
+    d = np.array([synth.pose_error(a, b) for a, b in zip(est_g, est_o)])
+    assert d[:, 0].max() < 1e-6 and d[:, 1].max() < 1e-6, (d.max(axis=0), int(d[:, 0].argmax()))
+    assert abs(rp.ate(est_g, truth) - rp.ate(est_o, truth)) < 1e-6
+    assert rp.ate(est_g, truth) < 0.3
+    assert all(r.status_extract == 0 for r in recs)
+    assert sum(1 for r in recs if r.status_mapping != 0) <= 2          # the map gate is only closed while the map is empty
+    assert recs[-1].grid_corner[0] > 1000 and recs[-1].grid_surf[0] > 10000
+    for k in ("corner", "surf"):                                       # same voxels; coordinates as close as the poses that placed them
+        assert maps_g[k].shape == maps_o[k].shape, (k, maps_g[k].shape, maps_o[k].shape)
+        assert np.abs(maps_g[k] - maps_o[k]).max() < 1e-4
+    if not pipelined:
+        test_device_resident_slam_step_matches_the_oracle_loop_over_300_scans.sync_poses = est_g
+    else:
+        ref = getattr(test_device_resident_slam_step_matches_the_oracle_loop_over_300_scans, "sync_poses", None)
+        if ref is not None:
+            assert np.array_equal(ref, est_g)
 
 
 @pytest.mark.gpu
