@@ -95,10 +95,7 @@ __device__ __forceinline__ int grid_dev_n(int n_cap, const int* __restrict__ n_d
   return n_dev ? min(max(*n_dev, 0), n_cap) : n_cap;
 }
 
-// ---- insert, step 0: reset the per-insert fields --------------------------------------------------------------------
-__global__ void grid_begin_kernel(GridState* __restrict__ st) {
-  st->bad = 0; st->overflow = 0; st->n_touched = 0; st->n_new_cells = 0; st->work = 0; st->delta_points = 0; st->n_big = 0;
-}
+// (the per-insert fields of GridState are left zeroed by grid_finish_kernel, so an insert needs no reset launch)
 
 // ---- insert, step 1: (optional) rigid transform + 63-bit key of every new point -------------------------------------
 // pose != null: p <- TransformPoint(pose, p) (laser_mapping.cc:24-31 / rigid_transform.h:131-137: f32 -> f64 -> q p + t -> f32),
@@ -365,6 +362,7 @@ __global__ void grid_finish_kernel(GridState* __restrict__ st, int* __restrict__
     report[0] = st->n_points; report[1] = st->n_cells; report[2] = st->pool_top; report[3] = st->bad; report[4] = st->overflow;
     report[5] = st->n_touched; report[6] = st->work; report[7] = st->surround_total;
   }
+  st->bad = 0; st->overflow = 0; st->n_touched = 0; st->n_new_cells = 0; st->work = 0; st->delta_points = 0; st->n_big = 0;
 }
 
 // ---- pool compaction / dump: the live cells back to back in table order -----------------------------------------------
@@ -387,7 +385,7 @@ grid_compact_kernel(const float4* __restrict__ pool_in, const int* __restrict__ 
 }
 
 // ---- GetSurroundedCloud ---------------------------------------------------------------------------------------------
-__global__ void grid_epoch_kernel(GridState* __restrict__ st) { st->epoch += 1; st->surround_total = 0; }
+// (the epoch a query stamps with is bumped at the END of the previous query's emit kernel; it starts at 1)
 
 // pass 1: stamp the cells hit by pose_f32 * p + (i,j,k) metres
 __global__ void __launch_bounds__(256)
@@ -408,11 +406,24 @@ grid_mark_kernel(const float4* __restrict__ scan, const int* __restrict__ idx, i
   const float wx = (p.x + qw * ux + cx) + (float)pose[0];
   const float wy = (p.y + qw * uy + cy) + (float)pose[1];
   const float wz = (p.z + qw * uz + cz) + (float)pose[2];
-  for (int i = -1; i <= 1; ++i)
-    for (int j = -1; j <= 1; ++j)
-      for (int k = -1; k <= 1; ++k) {
-        const unsigned long long key = grid_cell_key(grid_cell_index(wx + (float)i, resolution), grid_cell_index(wy + (float)j, resolution),
-                                                     grid_cell_index(wz + (float)k, resolution));
+  // The 27 probes (wx + i, wy + j, wz + k), i, j, k in {-1, 0, 1} (:476-485) hit few DISTINCT cells: per axis the three
+  // indices lround((w + o) / resolution) take one or two values when the cells are wider than 2 m (3 when narrower), so the
+  // distinct (x, y, z) combinations are looked up once each — 8 binary searches instead of 27 for the reference's 3 m cells.
+  int cxs[3], cys[3], czs[3], nx = 0, ny = 0, nz = 0;
+  for (int o = -1; o <= 1; ++o) {
+    const int a = grid_cell_index(wx + (float)o, resolution), b = grid_cell_index(wy + (float)o, resolution), c = grid_cell_index(wz + (float)o, resolution);
+    bool da = false, db = false, dc = false;
+    for (int q = 0; q < nx; q++) da = da || cxs[q] == a;
+    for (int q = 0; q < ny; q++) db = db || cys[q] == b;
+    for (int q = 0; q < nz; q++) dc = dc || czs[q] == c;
+    if (!da) cxs[nx++] = a;
+    if (!db) cys[ny++] = b;
+    if (!dc) czs[nz++] = c;
+  }
+  for (int i = 0; i < nx; ++i)
+    for (int j = 0; j < ny; ++j)
+      for (int k = 0; k < nz; ++k) {
+        const unsigned long long key = grid_cell_key(cxs[i], cys[j], czs[k]);
         if (key == kGridBadKey) continue;
         const int c = grid_find_cell(cell_keys, n_cells, key);
         if (c >= 0 && stamp[c] != epoch) stamp[c] = epoch;          // TryInsertGrid (:524-529)
@@ -440,6 +451,7 @@ grid_emit_kernel(const float4* __restrict__ pool, const int* __restrict__ cell_s
     for (int i = threadIdx.x; i < m; i += blockDim.x) if (o + i < capacity) out[o + i] = pool[s + i];
   }
   if (nc == 0 && blockIdx.x == 0 && threadIdx.x == 0) { st->surround_total = 0; if (n_out) *n_out = 0; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->epoch += 1;         // nothing in this kernel reads it: the next query stamps with a fresh value
 }
 
 }  // namespace msfl

@@ -28,7 +28,7 @@ slam_gather_kernel(const float4* __restrict__ full, const uint16_t* __restrict__
                    const int* __restrict__ ls_idx, const int* __restrict__ flat_idx, const int* __restrict__ lf_idx, int* __restrict__ cnt,
                    SlamCaps caps, float4* __restrict__ sharp_pts, float4* __restrict__ ls_pts, uint16_t* __restrict__ ls_ring,
                    float4* __restrict__ flat_pts, float4* __restrict__ lf_pts, uint16_t* __restrict__ lf_ring,
-                   const int* __restrict__ last_cnt, SlamCaps last_caps, int* __restrict__ odo_off) {
+                   const int* __restrict__ last_cnt, SlamCaps last_caps, int* __restrict__ odo_off, int* __restrict__ odo_status) {
   const int list = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool ok = cnt[SC_STATUS] == 0;
   const int n_sharp = ok ? min(cnt[SC_SHARP], caps.sharp) : 0, n_ls = ok ? min(cnt[SC_LESS_SHARP], caps.less_sharp) : 0;
@@ -41,8 +41,10 @@ slam_gather_kernel(const float4* __restrict__ full, const uint16_t* __restrict__
     odo_off[6] = 0; odo_off[7] = n_flat;
     odo_off[8] = 0; odo_off[9] = n_sharp + n_flat;
     // a list longer than the launch bound (a ring id beyond the configured ring count): reported, the scan is not matched
-    cnt[SC_OVERFLOW] = ok && (cnt[SC_SHARP] > caps.sharp || cnt[SC_LESS_SHARP] > caps.less_sharp || cnt[SC_FLAT] > caps.flat ||
-                              cnt[SC_LESS_FLAT] > caps.less_flat) ? 1 : 0;
+    const int over = ok && (cnt[SC_SHARP] > caps.sharp || cnt[SC_LESS_SHARP] > caps.less_sharp || cnt[SC_FLAT] > caps.flat ||
+                            cnt[SC_LESS_FLAT] > caps.less_flat) ? 1 : 0;
+    cnt[SC_OVERFLOW] = over;
+    *odo_status = (!ok || over) ? 3 /*MSFL_BAD_ARG: a scan without features is not matched*/ : 0;
   }
   if (list == 0) { if (i < n_sharp) sharp_pts[i] = full[sharp_idx[i]]; }
   else if (list == 1) { if (i < n_ls) { const int j = ls_idx[i]; ls_pts[i] = full[j]; ls_ring[i] = ring[j]; } }
