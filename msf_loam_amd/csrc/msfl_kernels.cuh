@@ -682,11 +682,13 @@ constexpr int kOdomLmBlock = MSFL_ODOM_LM_BLOCK;               // scan-to-scan: 
 // scan-to-scan problems, measured 0.365 ms per call vs 0.448 with 256 threads and 0.382 with 64), 17 KB x 8 (64:
 // one wavefront per problem, no cross-wave barrier)
 constexpr int lm_edge_cache(int block) { return block == 256 ? MSFL_LM_EDGE_CACHE : 0; }      // 60 B each
+// 512 threads: the one-solve-per-call SLAM step, where the machine is empty and a solve is as long as its chain of passes
+// (3 072 planes x 44 B = 132 KB, one workgroup per CU)
 constexpr int lm_plane_cache(int block) {
 #ifdef MSFL_LM_PLANE_CACHE
-  return block == 256 ? MSFL_LM_PLANE_CACHE : block == 128 ? 832 : 384;
+  return block == 256 ? MSFL_LM_PLANE_CACHE : block == 128 ? 832 : block == 512 ? 3072 : 384;
 #else
-  return block == 256 ? ((1728 - (lm_edge_cache(256) * 60 + 43) / 44) & ~63) : block == 128 ? 832 : 384;
+  return block == 256 ? ((1728 - (lm_edge_cache(256) * 60 + 43) / 44) & ~63) : block == 128 ? 832 : block == 512 ? 3072 : 384;
 #endif
 }
 template <int BLOCK>
