@@ -28,28 +28,40 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 ASSOC_KERNEL_PREFIX = "knn5_scan2map_kernel"   # the dominant kernel (rocprofv3 name prefix; template arguments follow)
 
 
-def build_inputs(B, map_points, seed_offset, extractor=None):
-    """Synthetic world/map (shared by all ranks) + this rank's B scans -> feature clouds."""
+def build_inputs(B, map_points, seed_offset, extractor=None, scan_ids=None, with_map=True):
+    """Synthetic world/map (shared by all ranks) + this rank's scans -> feature clouds.
+    Weak scaling: B scans seeded by the rank (`seed_offset`).  Strong scaling: `scan_ids` = this rank's block of GLOBAL
+    scan numbers; pose, guess and sensor noise of scan g depend on g alone, so the job is the same whatever the number
+    of ranks.  with_map=False: the caller receives the map by broadcast (rank 0 builds it)."""
     from msf_loam_amd import synth
     world = synth.World(ground_half=synth.ground_half_for_target(map_points))
-    map_corner, map_surf = synth.make_map(world)
-    poses = synth.random_poses(B, synth.SEED + 2 + 7919 * seed_offset)
-    rng = np.random.default_rng(synth.SEED + 3 + 7919 * seed_offset)
-    guesses = np.stack([synth.perturb_pose(p, rng) for p in poses])
+    map_corner, map_surf = synth.make_map(world) if with_map else (np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32))
+    if scan_ids is None:
+        poses = synth.random_poses(B, synth.SEED + 2 + 7919 * seed_offset)
+        rng = np.random.default_rng(synth.SEED + 3 + 7919 * seed_offset)
+        guesses = np.stack([synth.perturb_pose(p, rng) for p in poses])
+        scan_seeds = [synth.SEED + 100 + i + 100003 * seed_offset for i in range(B)]
+    else:
+        scan_ids = [int(g) for g in scan_ids]
+        B = len(scan_ids)
+        poses = np.stack([synth.random_poses(1, synth.SEED + 20000 + g)[0] for g in scan_ids]) if B else np.zeros((0, 7))
+        guesses = np.stack([synth.perturb_pose(poses[i], np.random.default_rng(synth.SEED + 40000 + g)) for i, g in enumerate(scan_ids)]) if B else np.zeros((0, 7))
+        scan_seeds = [synth.SEED + 60000 + g for g in scan_ids]
     corner, surf, co, so = [], [], [0], [0]
     raw = []
     for i in range(B):
-        pts, ring, kind = synth.make_scan(world, poses[i], synth.SEED + 100 + i + 100003 * seed_offset, with_kind=True)
+        pts, ring, kind = synth.make_scan(world, poses[i], scan_seeds[i], with_kind=True)
         raw.append((pts, ring, kind))
     if extractor is not None:
-        feats = extractor(raw)
+        feats = extractor(raw) if raw else []
     else:
         feats = [synth.direct_features(p, k) for p, _, k in raw]
     for c, s in feats:
         corner.append(c); surf.append(s)
         co.append(co[-1] + len(c)); so.append(so[-1] + len(s))
+    z = np.zeros((0, 4), np.float32)
     return dict(map_corner=map_corner, map_surf=map_surf, truth=poses, guesses=guesses,
-                corner=np.concatenate(corner), surf=np.concatenate(surf),
+                corner=np.concatenate(corner) if corner else z, surf=np.concatenate(surf) if surf else z,
                 corner_off=np.array(co, np.int32), surf_off=np.array(so, np.int32))
 
 
@@ -82,30 +94,43 @@ def product_extractor(handle):
     return run
 
 
-def cpu_baseline(inp, sample, threads):
-    """Oracle (CPU restatement of the reference algorithm, kd-tree rebuilt per registration like
-    mapping_scan_matcher.cc:66-73) timed on a bounded sample of the same workload."""
+def cpu_baseline(inp, sample, threads, reps=5):
+    """Oracle (CPU restatement of the reference algorithm) timed on the box's host cores, BASELINE.md §3 protocol: one
+    warm-up run, then the MEDIAN of `reps` runs, for both cost structures:
+      value           kd-trees rebuilt for every registration (the reference: mapping_scan_matcher.cc:66-73 builds them per call)
+      value_one_tree  one pair of kd-trees for the whole sample, built OUTSIDE the timed region (the GPU step indexes the
+                      map once per batch; a serial tree build inside the region would be most of the time on many cores)
+    The sample is the whole batch by default (>= 4 scans per hardware thread on a 256-thread host), so no thread idles."""
     from oracle import oracle as orc
     orc.build()
     n = min(sample, len(inp["guesses"]))
     co, so = inp["corner_off"][:n + 1], inp["surf_off"][:n + 1]
-    args = (inp["map_corner"], inp["map_surf"], inp["corner"][:co[-1]], co, inp["surf"][:so[-1]], so, inp["guesses"][:n])
+    corner, surf, guesses = inp["corner"][:co[-1]], inp["surf"][:so[-1]], inp["guesses"][:n]
     n1 = max(1, min(n, 16))
     t0 = time.perf_counter()
-    _, _, stages = orc.match_scan2map_batch_timed(args[0], args[1], inp["corner"][:co[n1]], co[:n1 + 1], inp["surf"][:so[n1]],
-                                                  so[:n1 + 1], inp["guesses"][:n1])
-    t1 = time.perf_counter()
-    single = n1 / (t1 - t0)
+    _, _, stages = orc.match_scan2map_batch_timed(inp["map_corner"], inp["map_surf"], inp["corner"][:co[n1]], co[:n1 + 1],
+                                                  inp["surf"][:so[n1]], so[:n1 + 1], inp["guesses"][:n1])
+    single = n1 / (time.perf_counter() - t0)
     stages_ms = {k: 1e3 * v / n1 for k, v in stages.items()}          # per registration, one thread
+
+    def timed(fn):
+        fn()                                                           # warm-up (page faults, thread pool)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = fn()
+            ts.append(time.perf_counter() - t0)
+        return out, float(np.median(ts)), ts
+
+    (poses, status), t_rebuild, all_rebuild = timed(lambda: orc.match_scan2map_batch(
+        inp["map_corner"], inp["map_surf"], corner, co, surf, so, guesses, threads=threads, rebuild_tree_per_scan=True))
     t0 = time.perf_counter()
-    poses, status = orc.match_scan2map_batch(*args, threads=threads, rebuild_tree_per_scan=True)
-    t1 = time.perf_counter()
-    # like-for-like with the GPU step, which indexes the map ONCE per batch: one kd-tree for the whole sample
-    t2 = time.perf_counter()
-    orc.match_scan2map_batch(*args, threads=threads, rebuild_tree_per_scan=False)
-    t3 = time.perf_counter()
-    return dict(value=n / (t1 - t0), value_one_tree=n / (t3 - t2), single_thread_value=single, n=n, n_single=n1, poses=poses,
-                stages_ms=stages_ms)
+    tc, ts_ = orc.KdTree(inp["map_corner"]), orc.KdTree(inp["map_surf"])
+    t_trees = time.perf_counter() - t0
+    _, t_one, all_one = timed(lambda: orc.match_scan2map_batch_trees(tc, ts_, corner, co, surf, so, guesses, threads=threads))
+    return dict(value=n / t_rebuild, value_one_tree=n / t_one, single_thread_value=single, n=n, n_single=n1, poses=poses,
+                stages_ms=stages_ms, reps=reps, tree_build_s=t_trees, runs_s=all_rebuild, runs_one_tree_s=all_one,
+                threads_busy=min(n, threads))
 
 
 def self_launch(n):
@@ -160,7 +185,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scans", type=int, default=1024, help="scans per GPU per step (BASELINE configs[1]: 1024)")
     ap.add_argument("--map-points", type=int, default=200000)
-    ap.add_argument("--cpu-sample", type=int, default=128, help="scans timed on the CPU oracle (0 disables)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --scans per GPU (the default; BASELINE configs[1] per rank); strong: --total-scans split over the ranks "
+                         "in contiguous blocks (the shape of configs[3]: one fixed batch sharded across the GPUs)")
+    ap.add_argument("--total-scans", type=int, default=0, help="strong scaling: scans of the whole job (default: --scans)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="scans timed on the CPU oracle (0 disables; default: the whole batch)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: leave the per-kernel HIP events off during the timed steps (roofline.achieved is then 0)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive leg (value_incl_h2d)")
@@ -200,13 +229,25 @@ def main():
 
     from msf_loam_amd import capi, dist as mdist
     h = capi.Handle(local_rank)
-    B = args.scans
+    strong = args.scaling == "strong"
+    total_scans = (args.total_scans or args.scans) if strong else world_size * args.scans
     extractor = None
     feature_source = args.features
     if feature_source == "product":
         extractor = product_extractor(h)
     t_prep = time.perf_counter()
-    inp = build_inputs(B, args.map_points, rank, extractor)
+    # rank 0 builds the local map, every other rank receives it by broadcast over the process group (scans
+    # sharded, map replicated); the scans are this rank's own (weak) or its block of the job's scans (strong)
+    if strong:
+        lo, hi = mdist.shard_bounds(total_scans, rank, world_size)
+        inp = build_inputs(0, args.map_points, rank, extractor, scan_ids=range(lo, hi), with_map=(rank == 0))
+    else:
+        inp = build_inputs(args.scans, args.map_points, rank, extractor, with_map=(rank == 0))
+    B = len(inp["guesses"])
+    if use_dist and world_size > 1:
+        bdev = torch.device("cpu") if shared_gpu else dev
+        mc_t, ms_t = mdist.broadcast_map(inp["map_corner"], inp["map_surf"], src=0, device=bdev)
+        inp["map_corner"], inp["map_surf"] = mc_t.cpu().numpy(), ms_t.cpu().numpy()
     t_prep = time.perf_counter() - t_prep
 
     stream = torch.cuda.current_stream(dev)
@@ -216,14 +257,16 @@ def main():
     d_corner = torch.from_numpy(inp["corner"]).to(dev)
     d_surf = torch.from_numpy(inp["surf"]).to(dev)
     d_guess = torch.from_numpy(inp["guesses"]).to(dev)
-    d_poses = torch.empty_like(d_guess)
-    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
-    gather = mdist.PoseGather(B, dev) if use_dist else None
+    # the pose gather sends equal blocks: in strong scaling the ranks' shares differ by at most one scan, padded to `cap`
+    cap = (total_scans + world_size - 1) // world_size if strong else B
+    d_poses = torch.zeros((cap, 7), dtype=torch.float64, device=dev)
+    d_status = torch.zeros(cap, dtype=torch.int32, device=dev)
+    gather = mdist.PoseGather(cap, dev) if use_dist else None
     n_mc, n_ms = len(inp["map_corner"]), len(inp["map_surf"])
     co, so = inp["corner_off"], inp["surf_off"]
 
     def step():
-        d_poses.copy_(d_guess)                                       # fresh initial guesses
+        d_poses[:B].copy_(d_guess)                                   # fresh initial guesses
         h.set_map(d_map_c, d_map_s, n_mc, n_ms, capi.MEM_DEVICE)      # kd-tree build equivalent, per batch
         h.match_scan2map_batch_device(B, d_corner, co, d_surf, so, d_poses, d_status)
         if gather is not None:
@@ -282,12 +325,24 @@ def main():
         elapsed = max(float(e.item()) for e in every)          # MAX over ranks
         rccl_ranks = dist.get_world_size()
 
-    poses_gpu = d_poses.cpu().numpy()
-    status_gpu = d_status.cpu().numpy()
+    poses_gpu = d_poses[:B].cpu().numpy()
+    status_gpu = d_status[:B].cpu().numpy()
+    poses_sha1 = None
+    if strong:
+        # every rank's block back in scan order (one more gather, outside the timed region): the job's result must not
+        # depend on how many ranks shared it
+        import hashlib
+        if use_dist and world_size > 1:
+            t_p = torch.from_numpy(poses_gpu).to(dev if not shared_gpu else "cpu"); t_s = torch.from_numpy(status_gpu).to(dev if not shared_gpu else "cpu")
+            all_p, all_s = mdist.gather_ragged(t_p, t_s, total_scans)
+            all_p = all_p.cpu().numpy()
+        else:
+            all_p = poses_gpu
+        poses_sha1 = hashlib.sha1(np.ascontiguousarray(all_p).tobytes()).hexdigest()
 
     if rank == 0:
         from msf_loam_amd import synth
-        total_regs = world_size * B * args.steps
+        total_regs = total_scans * args.steps
         value = total_regs / elapsed
         F_total = int(co[-1] + so[-1])
         n_outer = 2
@@ -313,12 +368,12 @@ def main():
         out = {
             "metric": "scan-to-map registrations/s", "value": value, "unit": "registrations/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "rccl_ranks": rccl_ranks, "ms_per_step_per_rank": rank_ms,
             "vs_baseline": None, "dtype": "f64 (f32 kNN distances)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: batch of %d VLP-16 scans (16x1800) vs %d-pt local map, "
                                    "2 outer x [exact 5-NN + line/plane fit, LM<=6 + Huber 0.1]" % (B, n_mc + n_ms),
-                       "scans_per_gpu": B, "map_points": n_mc + n_ms, "map_corner": n_mc, "map_surf": n_ms,
+                       "scans_per_gpu": B if not strong else cap, "total_scans": total_scans, "map_points": n_mc + n_ms, "map_corner": n_mc, "map_surf": n_ms,
                        "features_per_scan": F_total / B, "feature_source": feature_source,
                        "index_rebuilt_per_step": True, "parallelism": "scan-sharded x%d, map replicated" % world_size},
             "roofline": {"bound": "hbm", "kernel": "knn5_scan2map_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -338,6 +393,9 @@ def main():
             "prep_s": t_prep,
             "n_failed": int((status_gpu != 0).sum()),
         }
+        if strong:
+            out["poses_sha1"] = poses_sha1
+            out["config"]["map_source"] = "built on rank 0, broadcast over the process group" if world_size > 1 else "built on rank 0"
         out["value_incl_h2d"] = None               # N=1 only: the host-buffer call is a separate, untimed-for-`value` leg
         if world_size == 1 and not args.no_h2d:
             v, ms, nbytes = host_buffer_rate(h, inp, B)
@@ -350,8 +408,12 @@ def main():
             cb = cpu_baseline(inp, args.cpu_sample, cores)
             dts, drs = zip(*[synth.pose_error(poses_gpu[i], cb["poses"][i]) for i in range(cb["n"])])
             out["cpu_baseline"] = {"value": cb["value"], "unit": "registrations/s", "cores": cores, "kind": "port",
+                                   "threads_busy": cb["threads_busy"],
                                    "single_thread_value": cb["single_thread_value"],
                                    "value_one_tree_per_batch": cb["value_one_tree"],
+                                   "protocol": "warm-up 1, median of %d runs; runs (s): per-registration trees %s, one tree pair %s; "
+                                               "the shared kd-trees of value_one_tree_per_batch are built outside the timed region (%.3f s, serial)"
+                                               % (cb["reps"], ["%.3f" % t for t in cb["runs_s"]], ["%.3f" % t for t in cb["runs_one_tree_s"]], cb["tree_build_s"]),
                                    "like_for_like": "`value` rebuilds the kd-tree for every registration (the reference's cost "
                                                     "structure, mapping_scan_matcher.cc:66-73); `value_one_tree_per_batch` builds it "
                                                     "once for the sample, which is what the GPU step (one index build per batch) does",

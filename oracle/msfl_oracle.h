@@ -151,6 +151,9 @@ void orc_match_scan2map_batch(const orc_point* map_corner, int mc, const orc_poi
                               double* poses, int* status, int threads, int rebuild_tree_per_scan);
 
 /* Deskew variant (is_initialized branch; lidar_factor.cc:46-100; velocity block constant). */
+void orc_match_scan2map_batch_trees(const orc_point* map_corner, int mc, const orc_kdtree* tc, const orc_point* map_surf, int ms,
+                                    const orc_kdtree* ts, int n_scans, const orc_point* corner, const int* corner_off,
+                                    const orc_point* surf, const int* surf_off, double* poses, int* status, int threads);
 void orc_match_scan2map_batch_timed(const orc_point* map_corner, int mc, const orc_point* map_surf, int ms,
                                     int n_scans, const orc_point* corner, const int* corner_off,
                                     const orc_point* surf, const int* surf_off,

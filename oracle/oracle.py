@@ -230,6 +230,20 @@ def match_scan2map_batch(map_corner, map_surf, corner, corner_off, surf, surf_of
     return poses, status
 
 
+def match_scan2map_batch_trees(tree_corner, tree_surf, corner, corner_off, surf, surf_off, poses, threads=1):
+    """The batch against kd-trees (KdTree objects over the two map clouds) built by the caller beforehand."""
+    mc, ms = tree_corner.cloud, tree_surf.cloud
+    c, s = as_points(corner), as_points(surf)
+    co = np.ascontiguousarray(corner_off, dtype=np.int32)
+    so = np.ascontiguousarray(surf_off, dtype=np.int32)
+    poses = np.array(poses, dtype=np.float64).reshape(-1, 7).copy()
+    B = len(poses)
+    status = np.zeros(B, np.int32)
+    lib().orc_match_scan2map_batch_trees(_p(mc), C.c_int(len(mc)), tree_corner.h, _p(ms), C.c_int(len(ms)), tree_surf.h, C.c_int(B),
+                                         _p(c), _p(co), _p(s), _p(so), _p(poses), _p(status), C.c_int(threads))
+    return poses, status
+
+
 def match_scan2map_batch_timed(map_corner, map_surf, corner, corner_off, surf, surf_off, poses):
     """Single-threaded batch with the reference's LOG_STEP_TIME stages: returns (poses, status,
     {"build tree", "Data association", "Solver time"} seconds summed over the scans)."""

@@ -31,3 +31,28 @@ def test_two_ranks_print_one_whole_job_line(launched):
     assert d["rccl_ranks"] == 2 and len(d["ms_per_step_per_rank"]) == 2
     assert abs(max(d["ms_per_step_per_rank"]) - d["ms_per_step"]) < 1e-9
     assert d["n_failed"] == 0
+
+
+@pytest.mark.gpu
+def test_strong_scaling_shards_one_job_and_broadcasts_the_map():
+    """`--scaling strong --total-scans N` (the shape of BASELINE configs[3]): rank r registers shard_bounds(N, r, G) of ONE
+    job whose scans depend on their global number only, rank 0 builds the map and broadcasts it over the process group.
+    Two shared-GPU ranks must produce, scan for scan, the poses one rank produces (sha1 over the gathered poses), report
+    the whole job's rate, and an uneven split (N odd) must work."""
+    def run(nproc, port):
+        env = dict(os.environ, MSFL_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+        env.pop("RANK", None)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
+               "--scaling", "strong", "--total-scans", "65", "--cpu-sample", "0", "--no-h2d"]
+        out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        return json.loads(lines[0])
+    one, two = run(1, 29551), run(2, 29552)
+    for d, g in ((one, 1), (two, 2)):
+        assert d["scaling"] == "strong" and d["n_gpus"] == g and d["config"]["total_scans"] == 65 and d["n_failed"] == 0
+        assert abs(d["value"] - 65 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert two["config"]["scans_per_gpu"] == 33 and "broadcast" in two["config"]["map_source"]
+    assert one["poses_sha1"] == two["poses_sha1"], "the job's poses must not depend on the number of ranks"

@@ -89,3 +89,67 @@ def test_full_bench_batch_properties(gpu, oracle):
                                           inp["surf"][so[b]:so[b + 1]], inp["guesses"][b])
         dt, dr = synth.pose_error(poses[b], po)
         assert rc == 0 and dt < 1e-7 and dr < 1e-7
+
+
+def _share_properties(gpu, oracle, scans, copies, world, map_c, map_s, tag):
+    """A per-GPU share of a multi-GPU BASELINE config through the device-resident batch pipeline (extraction -> voxel
+    filters -> registration) and the size-independent properties of test_full_bench_batch_properties: bit-reproducible,
+    invariant under a permutation of the scans, every scan near its true pose, a sample of 3 against the oracle.
+    `scans` distinct sweeps are each registered from `copies` different initial guesses (registrations are independent
+    units, so repeating a sweep changes no property; synthesising every sweep separately would take minutes of numpy)."""
+    import torch
+    from msf_loam_amd.pipeline import BatchPipeline
+    dev = torch.device("cuda", 0)
+    B = len(scans) * copies
+    order = np.repeat(np.arange(len(scans)), copies)
+    truth = np.stack([scans[i][2] for i in order])
+    rng = np.random.default_rng(77)
+    guess = np.stack([synth.perturb_pose(p, rng, 0.3, 3.0) for p in truth])
+
+    def run(perm):
+        pts = np.concatenate([scans[order[b]][0] for b in perm]); ring = np.concatenate([scans[order[b]][1] for b in perm])
+        off = np.cumsum([0] + [len(scans[order[b]][0]) for b in perm]).astype(np.int32)
+        pipe = BatchPipeline(gpu, pts, ring, off, dev)
+        pipe.set_map(map_c, map_s)
+        d_guess = torch.from_numpy(guess[perm]).to(dev)
+        poses, status = pipe.run(d_guess)
+        torch.cuda.synchronize()
+        first = poses.cpu().numpy().copy()
+        poses, status = pipe.run(d_guess)
+        torch.cuda.synchronize()
+        assert np.array_equal(first, poses.cpu().numpy()), tag + ": bit-reproducible"
+        return first, status.cpu().numpy(), pipe
+
+    ident = np.arange(B)
+    poses, status, pipe = run(ident)
+    assert np.all(status == 0), (tag, int((status != 0).sum()))
+    err = np.array([synth.pose_error(poses[b], truth[b]) for b in range(B)])
+    assert err[:, 0].max() < 0.05 and err[:, 1].max() < 0.01, (tag, err.max(axis=0))
+    # a sample of three scans against the oracle, from the features the pipeline itself produced
+    co, so = pipe.corner_off, pipe.surf_off
+    for b in (0, B // 3, B - 1):
+        corner, surf = pipe.d_corner[co[b]:co[b + 1]].cpu().numpy(), pipe.d_surf[so[b]:so[b + 1]].cpu().numpy()
+        rc, po, _ = oracle.match_scan2map(map_c, map_s, corner, surf, guess[b])
+        dt, dr = synth.pose_error(poses[b], po)
+        assert rc == 0 and dt < 1e-6 and dr < 1e-6, (tag, b, dt, dr)
+    del pipe
+    perm = ident[::-1].copy()
+    rev, st2, _ = run(perm)
+    assert np.all(st2 == 0) and np.array_equal(rev[::-1], poses), tag + ": a registration does not depend on its neighbours in the batch"
+
+
+def test_config3_per_gpu_share_1250_64_beam_scans(gpu, oracle):
+    """BASELINE configs[3]: 10 000 64-beam scans (~110 k points each) over 8 GPUs = 1 250 per GPU, ~137 M points per batch."""
+    w, mc, ms = common.small_world(200000)
+    poses = synth.random_poses(25, synth.SEED + 640)
+    scans = [synth.make_scan(w, poses[i], synth.SEED + 641 + i, n_beams=64, n_az=1900, elev=(-24.8, 2.0)) + (poses[i],) for i in range(25)]
+    _share_properties(gpu, oracle, scans, 50, w, mc, ms, "configs[3] share")
+
+
+def test_config4_per_gpu_share_625_scans_vs_2m_point_map(gpu, oracle):
+    """BASELINE configs[4]: 5 000 concurrent registrations against a 2 M-point map over 8 GPUs = 625 per GPU."""
+    w = synth.World(ground_half=synth.ground_half_for_target(2_000_000))
+    mc, ms = synth.make_map(w)
+    poses = synth.random_poses(125, synth.SEED + 2500)
+    scans = [synth.make_scan(w, poses[i], synth.SEED + 2501 + i) + (poses[i],) for i in range(125)]
+    _share_properties(gpu, oracle, scans, 5, w, mc, ms, "configs[4] share")

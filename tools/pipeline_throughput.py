@@ -37,56 +37,15 @@ n = len(pts)
 torch.zeros(1, device=dev)
 h = capi.Handle(0)
 h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-lib = h.lib
-
-d_pts = torch.from_numpy(pts).to(dev)
-d_ring = torch.from_numpy(ring.astype(np.int16)).to(dev)
-d_full = torch.empty((n, 4), dtype=torch.float32, device=dev)
-d_fring = torch.empty(n, dtype=torch.int16, device=dev)
-d_curv = torch.empty(n, dtype=torch.float32, device=dev)
-d_label = torch.empty(n, dtype=torch.uint8, device=dev)
-d_idx = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4)]
-d_cnt = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(5)]
-d_status = torch.empty(B, dtype=torch.int32, device=dev)
-d_corner = torch.empty((n, 4), dtype=torch.float32, device=dev)
-d_surf = torch.empty((n, 4), dtype=torch.float32, device=dev)
-d_map_c = torch.from_numpy(map_c).to(dev)
-d_map_s = torch.from_numpy(map_s).to(dev)
+from msf_loam_amd.pipeline import BatchPipeline
+pipe = BatchPipeline(h, pts, ring, off, dev)
+pipe.set_map(map_c, map_s)
 d_guess = torch.from_numpy(guess).to(dev)
-d_poses = torch.empty_like(d_guess)
-d_mstat = torch.zeros(B, dtype=torch.int32, device=dev)
-corner_off = np.zeros(B + 1, np.int32)
-surf_off = np.zeros(B + 1, np.int32)
-
-f = capi.FeaturesBatch()
-f.full_pts, f.full_ring, f.curvature, f.label = d_full.data_ptr(), d_fring.data_ptr(), d_curv.data_ptr(), d_label.data_ptr()
-f.sharp_idx, f.less_sharp_idx, f.flat_idx, f.less_flat_idx = (t.data_ptr() for t in d_idx)
-f.n_full, f.n_sharp, f.n_less_sharp, f.n_flat, f.n_less_flat = (t.data_ptr() for t in d_cnt)
-vp = C.c_void_p
-
-
-def check(s, what):
-    if s != 0:
-        raise RuntimeError("%s: status %d %s" % (what, s, lib.msfl_last_error(h.h).decode()))
-
-
-def extract():
-    check(lib.msfl_extract_features_batch(h.h, C.c_int(B), vp(d_pts.data_ptr()), vp(d_ring.data_ptr()), off.ctypes.data_as(vp), C.byref(f),
-                                          vp(d_status.data_ptr()), C.c_int(capi.MEM_DEVICE)), "extract")
-
-
-def voxel():
-    # corner (0.2 m) and surf (0.4 m) lists in one call: both filters are enqueued before the one synchronisation
-    check(lib.msfl_voxel_downsample_batch_pair(h.h, C.c_int(B), vp(d_full.data_ptr()), off.ctypes.data_as(vp),
-                                               vp(d_idx[1].data_ptr()), vp(d_cnt[2].data_ptr()), C.c_float(0.2), vp(d_corner.data_ptr()), corner_off.ctypes.data_as(vp),
-                                               vp(d_idx[3].data_ptr()), vp(d_cnt[4].data_ptr()), C.c_float(0.4), vp(d_surf.data_ptr()), surf_off.ctypes.data_as(vp),
-                                               C.c_int(capi.MEM_DEVICE)), "voxel corner + surf")
+extract, voxel = pipe.extract, pipe.voxel
 
 
 def register():
-    d_poses.copy_(d_guess)
-    h.set_map(d_map_c, d_map_s, len(map_c), len(map_s), capi.MEM_DEVICE)
-    h.match_scan2map_batch_device(B, d_corner, corner_off, d_surf, surf_off, d_poses, d_mstat)
+    pipe.register(d_guess)
 
 
 def timed(fn, k):
@@ -109,7 +68,8 @@ gc.collect(); gc.disable()                                   # a gen-2 collectio
 t_ext, t_vox, t_reg = timed(extract, STEPS), timed(voxel, STEPS), timed(register, STEPS)
 t_ext2 = timed(extract, STEPS)
 t_all = timed(whole, STEPS)
-poses = d_poses.cpu().numpy()
+poses = pipe.d_poses.cpu().numpy()
+corner_off, surf_off, d_mstat = pipe.corner_off, pipe.surf_off, pipe.d_mstat
 err_t = max(synth.pose_error(poses[i], truth[i])[0] for i in range(B))
 err_r = max(synth.pose_error(poses[i], truth[i])[1] for i in range(B))
 
