@@ -17,6 +17,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -189,6 +190,15 @@ class OdometryScanMatcher : public ScanMatcher {
 class MappingScanMatcher : public ScanMatcher {
  public:
   using ScanMatcher::ScanMatcher;
+  // The IMU-only pre-solve of the is_initialized branch (mapping_scan_matcher.cc:28-59): ONE IMUFactor over
+  // prev_state.imu_preintegration, pose_i / bias_i constant, 6 LM iterations, whose pose_j and bias_j.head<3>() REPLACE
+  // the incoming *pose_estimate_map_scan2world and *velocity (.cc:58-59) before the LiDAR loop starts.  It is a 15-residual
+  // CPU problem on the maintainer's side of the boundary (Ceres + IMUFactor, SURVEY.md 8f N3: "the pre-solve stays on the
+  // CPU"), so it is installed as a hook: called with prev_state, it must write the two outputs.  The eight-argument
+  // MatchScan2Map refuses to run the is_initialized branch without it rather than silently start from the caller's pose.
+  using ImuPresolve = std::function<void(const RobotState& prev_state, Rigid3d* pose_j, Vector3d* velocity_j)>;
+  void SetImuPresolve(ImuPresolve f) { imu_presolve_ = std::move(f); }
+
   // cloud_map / scan_curr: only cloud_corner_less_sharp and cloud_surf_less_flat are read
   // (mapping_scan_matcher.cc:71-72,109,179).  `deskew` non-null selects the is_initialized branch
   // (per-point time comes from PointXYZI::intensity, .cc:114); `velocity` is read as Vi and written
@@ -231,9 +241,11 @@ class MappingScanMatcher : public ScanMatcher {
   //   !is_initialized: LiDAR-only branch (.cc:96,123); preintegration / gravity_vector / prev_state are not read.
   //   is_initialized : GetDeltaQP(preintegration, point.intensity) for every feature point (.cc:112-116,182-186) runs on
   //                    the GPU (msfl_delta_qp), then the Deskew factors with the velocity block held constant (.cc:94).
-  //                    The IMU-only pre-solve the reference runs first (.cc:35-59: one IMUFactor, 15 residuals, CPU,
-  //                    out of scope per SURVEY.md 8f N3) is NOT repeated here: *pose_estimate_map_scan2world and *velocity
-  //                    are taken as its outputs (pose_j, bias_j.head<3>()), which is what the reference's loop reads (.cc:83,107).
+  //                    The IMU-only pre-solve the reference runs first (.cc:28-59) is the hook installed with
+  //                    SetImuPresolve: it is called with prev_state and overwrites *pose_estimate_map_scan2world and
+  //                    *velocity (pose_j, bias_j.head<3>(): what the reference's loop then reads, .cc:83,107), exactly
+  //                    like .cc:58-59 — the incoming pose is NOT the starting point of this branch.  Without a hook the
+  //                    call throws std::logic_error.
   // A feature time outside the pre-integration span aborts in the reference (CHECK, scan_undistortion.cc:26-30): exception here.
   bool MatchScan2Map(const TimestampedPointCloud<PointType>& cloud_map,
                      const TimestampedPointCloud<PointType>& scan_curr,
@@ -243,9 +255,13 @@ class MappingScanMatcher : public ScanMatcher {
                      const RobotState& prev_state,
                      Rigid3d* pose_estimate_map_scan2world,
                      Vector3d* velocity) {
-    (void)prev_state;                                                  // only feeds the pre-solve and a log line (.cc:27)
-    if (!is_initialized)
+    if (!is_initialized)                                               // prev_state only feeds the pre-solve and a log line (.cc:27)
       return MatchScan2Map(cloud_map, scan_curr, false, nullptr, pose_estimate_map_scan2world, velocity);
+    if (!imu_presolve_)
+      throw std::logic_error("MatchScan2Map(is_initialized): no IMU pre-solve installed (SetImuPresolve); the reference starts this "
+                             "branch from the IMU-only solve of prev_state (mapping_scan_matcher.cc:28-59), not from the incoming pose");
+    if (!pose_estimate_map_scan2world || !velocity) throw std::invalid_argument("MatchScan2Map: null pose / velocity");
+    imu_presolve_(prev_state, pose_estimate_map_scan2world, velocity);  // .cc:58-59
     if (!preintegration || preintegration->sum_dt_buf_.size() < 2 ||
         preintegration->delta_q_buf_.size() != preintegration->sum_dt_buf_.size() ||
         preintegration->delta_p_buf_.size() != preintegration->sum_dt_buf_.size())
@@ -269,6 +285,9 @@ class MappingScanMatcher : public ScanMatcher {
                                   MSFL_MEM_HOST), h_, "msfl_delta_qp (surf)");
     return MatchScan2Map(cloud_map, scan_curr, true, &d, pose_estimate_map_scan2world, velocity);
   }
+
+ private:
+  ImuPresolve imu_presolve_;
 };
 
 // RealHandleLaserCloudMessage (msf_loam_node.cc:160-378) between pcl::fromROSMsg and AddLaserScan.

@@ -7,6 +7,7 @@
 //        | 7 f64 map pose of the 8-argument call, is_initialized = true (deskew branch)
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
 #include <vector>
 
 #include "msfl/scan_matcher.hpp"
@@ -59,9 +60,21 @@ int main(int argc, char** argv) {
   msfl::Rigid3d pose8(std::array<double, 7>{{guess[0], guess[1], guess[2], guess[3], guess[4], guess[5], guess[6]}});
   msfl::Vector3d vel8{{0, 0, 0}};
   const bool ok8 = mapper.MatchScan2Map(map, cur, false, pre, gravity, prev, &pose8, &vel8);
-  msfl::Rigid3d pose8d(std::array<double, 7>{{guess[0], guess[1], guess[2], guess[3], guess[4], guess[5], guess[6]}});
-  msfl::Vector3d vel8d{{vel_in[0], vel_in[1], vel_in[2]}};
-  const bool ok8d = mapper.MatchScan2Map(map, cur, true, pre, gravity, prev, &pose8d, &vel8d);
+  // is_initialized: the reference starts from its IMU-only pre-solve of prev_state (mapping_scan_matcher.cc:28-59), not from the
+  // incoming pose.  Without the hook the mirror must refuse; with it, the hook's outputs are the starting point whatever comes in.
+  msfl::Rigid3d pose8d = msfl::Rigid3d::Identity();                       // deliberately NOT the guess
+  msfl::Vector3d vel8d{{0, 0, 0}};
+  bool refused = false;
+  try { mapper.MatchScan2Map(map, cur, true, pre, gravity, prev, &pose8d, &vel8d); } catch (const std::logic_error&) { refused = true; }
+  if (!refused) return 4;
+  int hook_calls = 0;
+  prev.time = 42.0;
+  mapper.SetImuPresolve([&](const msfl::RobotState& ps, msfl::Rigid3d* pose_j, msfl::Vector3d* vel_j) {
+    if (ps.time == 42.0 && ps.imu_preintegration == pre) ++hook_calls;
+    *pose_j = msfl::Rigid3d(std::array<double, 7>{{guess[0], guess[1], guess[2], guess[3], guess[4], guess[5], guess[6]}});
+    *vel_j = msfl::Vector3d{{vel_in[0], vel_in[1], vel_in[2]}};
+  });
+  const bool ok8d = mapper.MatchScan2Map(map, cur, true, pre, gravity, prev, &pose8d, &vel8d) && hook_calls == 1;
   FILE* o = fopen(argv[2], "wb");
   auto v = pose.ToVector7(); auto w = rel.ToVector7();
   fwrite(v.data(), 8, 7, o); fwrite(w.data(), 8, 7, o);
