@@ -394,12 +394,9 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
     }
     {
       ScopedTimer timer(h, T_SOLVE);
-      if (deskew)
-        hipLaunchKernelGGL((lm_solve_kernel<kLmBlock, false>), dim3(B), dim3(kLmBlock), 0, st, bv, (const double*)dv.pprime,
-                           (const double*)h->records.as<double>(), d_poses, d_status, d_info, it, sp);
-      else
-        hipLaunchKernelGGL((lm_solve_kernel<kLmBlock, kLmPacked>), dim3(B), dim3(kLmBlock), 0, st, bv, (const double*)nullptr,
-                           (const double*)h->records.as<double>(), d_poses, d_status, d_info, it, sp);
+      hipLaunchKernelGGL(lm_solve_kernel<kLmBlock>, dim3(B), dim3(kLmBlock), 0, st, bv,
+                         deskew ? (const double*)dv.pprime : (const double*)nullptr,
+                         (const double*)h->records.as<double>(), d_poses, d_status, d_info, it, sp);
     }
   }
   HIPCHK(h, hipGetLastError());
@@ -833,7 +830,7 @@ msfl_status msfl_solve_records(msfl_handle* h, const msfl_point* corner, int n_c
   if (n) {
     HIPCHK(h, h->pprime.reserve((size_t)n * 6 * sizeof(double)));
     HIPCHK(h, hipMemcpyAsync(h->pprime.p, records, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(pack_records_kernel<kLmPacked>, dim3(div_up(n, 256)), dim3(256), 0, h->stream, bv, (const double*)h->pprime.as<double>(),
+    hipLaunchKernelGGL(pack_records_kernel, dim3(div_up(n, 256)), dim3(256), 0, h->stream, bv, (const double*)h->pprime.as<double>(),
                        h->records.as<double>());
   }
   DevMatchInfo* d_info = nullptr;
@@ -844,7 +841,7 @@ msfl_status msfl_solve_records(msfl_handle* h, const msfl_point* corner, int n_c
   }
   {
     ScopedTimer timer(h, T_SOLVE);
-    hipLaunchKernelGGL((lm_solve_kernel<kLmBlock, kLmPacked>), dim3(1), dim3(kLmBlock), 0, h->stream, bv, (const double*)nullptr,
+    hipLaunchKernelGGL(lm_solve_kernel<kLmBlock>, dim3(1), dim3(kLmBlock), 0, h->stream, bv, (const double*)nullptr,
                        (const double*)h->records.as<double>(), h->poses.as<double>(), h->status.as<int>(), d_info, 0,
                        solver_params(h->prm, 0));
   }

@@ -15,7 +15,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <type_traits>
 
 #include "msfl_math.cuh"
 
@@ -462,19 +461,6 @@ __device__ __forceinline__ size_t edge_rec_off(const BatchView& bv, int fi_corne
   return 4 * (size_t)bv.n_surf_total + 6 * (size_t)(fi_corner - bv.c0);
 }
 
-// Packed plane record of the plain (LiDAR-only) scan-to-map solve: the unit normal in f32, the feature point it belongs
-// to, and the offset d0 = N32 . C in f64 — one aligned 32-byte line per record instead of a 32-byte {N, d0} record plus a
-// 16-byte point from another array (48 -> 32 bytes per record and pass of the bandwidth-bound solve, 30 % more records in
-// its LDS cache).  d0 is formed from the ROUNDED normal, so the plane (N32, d0) still passes through the fitted centre C
-// exactly: the residual N32 . (R p + t - C) differs from the f64-normal one by the normal's 6e-8 rad tilt times the
-// point's distance to C (< 1 m: the five neighbours are within the 1 m gate), i.e. < 1e-7 m per residual.
-struct PlaneRec { float nx, ny, nz, px, py, pz; double d0; };
-static_assert(sizeof(PlaneRec) == 32, "a packed plane record takes the slot of a {N, d0} record");
-#ifndef MSFL_LM_PACKED
-#define MSFL_LM_PACKED 1
-#endif
-constexpr bool kLmPacked = MSFL_LM_PACKED != 0;     // plain scan-to-map records (the deskew branch and scan-to-scan keep {N, d0} in f64)
-
 struct DeskewView {
   // all null for the plain (LiDAR-only) branch
   const double* corner_dq; const double* corner_dp;
@@ -592,17 +578,6 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
     double* out = rec + edge_rec_off(bv, bv.corner_off[b] + local);
     out[0] = fo.C.x; out[1] = fo.C.y; out[2] = fo.C.z;
     out[3] = fo.N.x; out[4] = fo.N.y; out[5] = fo.N.z;
-  } else if (!DESKEW && kLmPacked) {
-    const int fi = bv.surf_off[b] + (local - nc);
-    const float4 f = bv.surf[fi];
-    PlaneRec r;
-    r.nx = (float)fo.N.x; r.ny = (float)fo.N.y; r.nz = (float)fo.N.z;
-    r.px = f.x; r.py = f.y; r.pz = f.z;
-    r.d0 = (double)r.nx * fo.C.x + (double)r.ny * fo.C.y + (double)r.nz * fo.C.z;
-    if (fo.N.x != 0.0 || fo.N.y != 0.0 || fo.N.z != 0.0) {      // an accepted fit must not round to the "rejected" marker
-      if (r.nx == 0.f && r.ny == 0.f && r.nz == 0.f) r.nx = 1e-30f;
-    }
-    *reinterpret_cast<PlaneRec*>(rec + plane_rec_off(bv, fi)) = r;
   } else {
     double* out = rec + plane_rec_off(bv, bv.surf_off[b] + (local - nc));
     out[0] = fo.N.x; out[1] = fo.N.y; out[2] = fo.N.z; out[3] = dot(fo.N, fo.C);
@@ -614,7 +589,6 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
 }
 
 // {C, N} x n_records (host/debug format) -> compact internal records
-template <bool PACKED>
 __global__ void __launch_bounds__(256) pack_records_kernel(BatchView bv, const double* __restrict__ full, double* __restrict__ rec) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= batch_records(bv)) return;
@@ -626,15 +600,6 @@ __global__ void __launch_bounds__(256) pack_records_kernel(BatchView bv, const d
     double* out = rec + edge_rec_off(bv, bv.corner_off[b] + local);
 #pragma unroll
     for (int k = 0; k < 6; k++) out[k] = in[k];
-  } else if (PACKED) {
-    const int fi = bv.surf_off[b] + (local - nc);
-    const float4 f = bv.surf[fi];
-    PlaneRec r;
-    r.nx = (float)in[3]; r.ny = (float)in[4]; r.nz = (float)in[5];
-    r.px = f.x; r.py = f.y; r.pz = f.z;
-    r.d0 = (double)r.nx * in[0] + (double)r.ny * in[1] + (double)r.nz * in[2];
-    if ((in[3] != 0.0 || in[4] != 0.0 || in[5] != 0.0) && r.nx == 0.f && r.ny == 0.f && r.nz == 0.f) r.nx = 1e-30f;
-    *reinterpret_cast<PlaneRec*>(rec + plane_rec_off(bv, fi)) = r;
   } else {
     double* out = rec + plane_rec_off(bv, bv.surf_off[b] + (local - nc));
     out[0] = in[3]; out[1] = in[4]; out[2] = in[5]; out[3] = in[3] * in[0] + in[4] * in[1] + in[5] * in[2];
@@ -726,12 +691,10 @@ constexpr int lm_plane_cache(int block) {
   return block == 256 ? ((1728 - (lm_edge_cache(256) * 60 + 43) / 44) & ~63) : block == 128 ? 832 : block == 512 ? 3072 : 384;
 #endif
 }
-template <int BLOCK, bool PACKED = false>
+template <int BLOCK>
 struct PlaneCache {
-  // packed records are 32 B in the cache too (f32 normal): the same LDS holds 44 / 32 as many of them
-  static constexpr int kPlanes = PACKED ? ((lm_plane_cache(BLOCK) * 44 / 32) & ~63) : lm_plane_cache(BLOCK), kEdges = lm_edge_cache(BLOCK);
-  typename std::conditional<PACKED, float, double>::type nx[kPlanes], ny[kPlanes], nz[kPlanes];
-  double d0[kPlanes];
+  static constexpr int kPlanes = lm_plane_cache(BLOCK), kEdges = lm_edge_cache(BLOCK);
+  double nx[kPlanes], ny[kPlanes], nz[kPlanes], d0[kPlanes];
   float px[kPlanes], py[kPlanes], pz[kPlanes];
   double ecx[kEdges + 1], ecy[kEdges + 1], ecz[kEdges + 1], enx[kEdges + 1], eny[kEdges + 1], enz[kEdges + 1];
   float epx[kEdges + 1], epy[kEdges + 1], epz[kEdges + 1];
@@ -761,14 +724,14 @@ __device__ unsigned long long g_lm_prof[8];   // cycles (lane 0, summed over wor
 
 __device__ __forceinline__ d3 lm_rotate(const quat& q, d3 v) { return quat_rotate(q, v); }
 
-template <int BLOCK, bool FILL, bool PACKED>
+template <int BLOCK, bool FILL>
 __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
                                               const float4* __restrict__ corner, int nc,
                                               const float4* __restrict__ surf, int ns,
                                               const double* __restrict__ pprime,   // may be null
                                               const double* __restrict__ rec,      // this scan's edge records
                                               const double* __restrict__ recp,     // this scan's plane records
-                                              PlaneCache<BLOCK, PACKED>& pc, EdgeList& el,
+                                              PlaneCache<BLOCK>& pc, EdgeList& el,
                                               double (&acc)[kAcc], int& n_edge, int& n_plane) {
 #pragma unroll
   for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
@@ -783,7 +746,7 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
     const bool listed = !FILL && k < n_listed;
     const int i = FILL ? k : (listed ? (int)el.idx[k] : kEdgeListMax + (k - n_listed));
     d3 C, N, p;
-    if (!FILL && pprime == nullptr && i < PlaneCache<BLOCK, PACKED>::kEdges) {
+    if (!FILL && pprime == nullptr && i < PlaneCache<BLOCK>::kEdges) {
       C = mk3(pc.ecx[i], pc.ecy[i], pc.ecz[i]); N = mk3(pc.enx[i], pc.eny[i], pc.enz[i]);
       p = mk3((double)pc.epx[i], (double)pc.epy[i], (double)pc.epz[i]);
     } else {
@@ -794,7 +757,7 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
       else {
         const float4 f = corner[i];                              // curr_point: untransformed (:146)
         p = mk3((double)f.x, (double)f.y, (double)f.z);
-        if (FILL && i < PlaneCache<BLOCK, PACKED>::kEdges) {
+        if (FILL && i < PlaneCache<BLOCK>::kEdges) {
           pc.ecx[i] = C.x; pc.ecy[i] = C.y; pc.ecz[i] = C.z; pc.enx[i] = N.x; pc.eny[i] = N.y; pc.enz[i] = N.z;
           pc.epx[i] = f.x; pc.epy[i] = f.y; pc.epz[i] = f.z;
         }
@@ -852,8 +815,8 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   // (a) the LDS-resident head of the plane list (later passes; a thread reads back what it wrote itself)
   int i = threadIdx.x;
   if (!FILL && use_cache) {
-    for (; i < min(ns, PlaneCache<BLOCK, PACKED>::kPlanes); i += BLOCK)
-      plane_row(mk3((double)pc.nx[i], (double)pc.ny[i], (double)pc.nz[i]), pc.d0[i], mk3((double)pc.px[i], (double)pc.py[i], (double)pc.pz[i]));
+    for (; i < min(ns, PlaneCache<BLOCK>::kPlanes); i += BLOCK)
+      plane_row(mk3(pc.nx[i], pc.ny[i], pc.nz[i]), pc.d0[i], mk3((double)pc.px[i], (double)pc.py[i], (double)pc.pz[i]));
   }
   // (b) the streamed rest (everything in the FILL pass).  The solve is bound by these re-reads: ~1 GB per launch at
   // ~4.4 TB/s with all 1 024 solves resident (PMC r02).  Measured and rejected: software pipelining the loads 1 / 2 / 3
@@ -861,15 +824,6 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   // pass); solving the batch in 2 / 4 launches of fewer scans (0.41 / 0.71 ms: with fewer resident workgroups the
   // pass becomes latency bound instead).
   for (; i < ns; i += BLOCK) {
-    if (PACKED) {                                                 // one 32-byte line: normal, point, offset
-      const PlaneRec r = *reinterpret_cast<const PlaneRec*>(recp + 4 * (size_t)i);
-      if (FILL && i < PlaneCache<BLOCK, PACKED>::kPlanes) {
-        pc.nx[i] = r.nx; pc.ny[i] = r.ny; pc.nz[i] = r.nz; pc.d0[i] = r.d0;
-        pc.px[i] = r.px; pc.py[i] = r.py; pc.pz[i] = r.pz;
-      }
-      plane_row(mk3((double)r.nx, (double)r.ny, (double)r.nz), r.d0, mk3((double)r.px, (double)r.py, (double)r.pz));
-      continue;
-    }
     const double* r4 = recp + 4 * (size_t)i;
     const d3 N = mk3(r4[0], r4[1], r4[2]); const double d0 = r4[3];
     d3 p;
@@ -877,7 +831,7 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
     else {
       const float4 f = surf[i];                                  // curr_point: untransformed (:221)
       p = mk3((double)f.x, (double)f.y, (double)f.z);
-      if (FILL && i < PlaneCache<BLOCK, PACKED>::kPlanes) {
+      if (FILL && i < PlaneCache<BLOCK>::kPlanes) {
         pc.nx[i] = N.x; pc.ny[i] = N.y; pc.nz[i] = N.z; pc.d0[i] = d0;
         pc.px[i] = f.x; pc.py[i] = f.y; pc.pz[i] = f.z;
       }
@@ -1162,13 +1116,13 @@ __device__ __noinline__ int tr_decide(TrState& tr, const double* red, const Solv
 #ifndef MSFL_LM_WAVES
 #define MSFL_LM_WAVES 2
 #endif
-template <int BLOCK, bool PACKED = false>
+template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK, MSFL_LM_WAVES)
 lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const double* __restrict__ rec_all,
                 double* __restrict__ poses, int* __restrict__ status, DevMatchInfo* __restrict__ info,
                 int outer_it, SolverParams prm) {
   __shared__ LmShared<BLOCK> sh;
-  __shared__ PlaneCache<BLOCK, PACKED> s_cache;
+  __shared__ PlaneCache<BLOCK> s_cache;
   __shared__ EdgeList s_edges;
   const int b = blockIdx.x;
   if (status[b] != 0) return;
@@ -1190,7 +1144,7 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
     int ne, np;
     const pose7 T = load_pose(pose_g);
     LM_T(t0);
-    evaluate_pass<BLOCK, true, PACKED>(T, prm.huber, corner, nc, surf, ns, pprime, rec, recp, s_cache, s_edges, acc, ne, np);
+    evaluate_pass<BLOCK, true>(T, prm.huber, corner, nc, surf, ns, pprime, rec, recp, s_cache, s_edges, acc, ne, np);
     LM_T(t1);
     block_reduce<BLOCK>(sh, acc, ne, np);
     LM_T(t2);
@@ -1250,7 +1204,7 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
     const pose7 T = load_pose(tr.cand);   // lane 0 overwrites go / cand only after the reduction's barrier, which every
                                            // thread reaches after this read: no barrier of its own needed
     LM_T(t0);
-    evaluate_pass<BLOCK, false, PACKED>(T, prm.huber, corner, nc, surf, ns, pprime, rec, recp, s_cache, s_edges, acc, ne, np);
+    evaluate_pass<BLOCK, false>(T, prm.huber, corner, nc, surf, ns, pprime, rec, recp, s_cache, s_edges, acc, ne, np);
     LM_T(t1);
     block_reduce<BLOCK>(sh, acc, ne, np);
     LM_T(t2);
