@@ -163,6 +163,34 @@ def pmc_traffic(kernel_prefix):
     return sum(pt["kernels"][k]["hbm_bytes_per_launch"] for k in hits), pt["source"]
 
 
+def valu_roof(kernel_prefix, launch_ms):
+    """VALU issue roof of the dominant kernel (profiles/r03_valu_rate.md): wave-instructions per launch from the committed
+    PMC profile x the kernel's static mix of 2.25-clock and 4.3-clock instructions (tools/valu_model.py from the ISA, issue
+    rates measured by tools/ubench/valu_rate.hip), over the SIMD-clocks one launch has: 1 024 SIMDs x 2.4 GHz x its duration.
+    None when either committed file is missing or does not hold the kernel."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f)
+        with open(os.path.join(ROOT, "profiles", "r03_valu_mix.json")) as f:
+            mix = json.load(f)
+    except OSError:
+        return None
+    hit = [k for k in pt["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>") and "sq_insts_valu" in pt["kernels"][k]]
+    mk = [k for k in mix["kernels"] if k.replace(" ", "") == kernel_prefix + "<false,false>"] or \
+         [k for k in mix["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>")]
+    if not hit or not mk or launch_ms <= 0:
+        return None
+    insts = pt["kernels"][hit[0]]["sq_insts_valu"]
+    m = mix["kernels"][mk[0]]
+    clk = m["clocks_per_inst_static_mix"]
+    simd_clocks = 1024 * 2.4e9 * launch_ms * 1e-3
+    return {"wave_insts_per_launch": insts, "clocks_per_inst": clk, "clocks_per_inst_class": mix["clocks"],
+            "static_mix": {"fast_2clk": m["fast_2clk"], "four_clk": m["four_clk"], "slow": m["slow"]},
+            "simd_clocks_needed": insts * clk, "simd_clocks_available": simd_clocks, "frac": insts * clk / simd_clocks,
+            "source": "SQ_INSTS_VALU: %s; mix: profiles/r03_valu_mix.json (static ISA counts); rates: profiles/r03_valu_rate.md; "
+                      "clock 2.4 GHz x 256 CUs x 4 SIMDs" % pt["source"].split(" (")[0]}
+
+
 def host_buffer_rate(h, inp, B, reps=5):
     """PCIe-inclusive rate (batch wall time incl. H2D of the features, excl. the one-time map
     upload / index): features, guesses and results in pinned host memory, the map resident and indexed."""
@@ -363,6 +391,8 @@ def main():
         # whole step: every outer iteration reads each feature and its five neighbours once, the map once per batch,
         # one pose in and out per scan; kernels in between communicate through HBM, which is not
         # algorithmic
+        valu = valu_roof(ASSOC_KERNEL_PREFIX, assoc_ms) if (B == 1024 and args.map_points == 200000) else None
+        roof_bound = "valu" if (valu is not None and valu["frac"] > achieved / HBM_PEAK_GBS) else "hbm"
         alg_bytes_step = n_outer * F_total * 96 + (n_mc + n_ms) * 16 + B * 112
         step_s = elapsed / args.steps
         out = {
@@ -376,9 +406,12 @@ def main():
                        "scans_per_gpu": B if not strong else cap, "total_scans": total_scans, "map_points": n_mc + n_ms, "map_corner": n_mc, "map_surf": n_ms,
                        "features_per_scan": F_total / B, "feature_source": feature_source,
                        "index_rebuilt_per_step": True, "parallelism": "scan-sharded x%d, map replicated" % world_size},
-            "roofline": {"bound": "hbm", "kernel": "knn5_scan2map_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": roof_bound, "kernel": "knn5_scan2map_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes_assoc, "avg_launch_ms": assoc_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes_assoc, "avg_launch_ms": assoc_ms, "valu": valu,
+                         "bound_note": "achieved / peak / frac are the HBM figures on ALGORITHMIC bytes (SURVEY.md 8d); `bound` names the roof the "
+                                       "kernel is nearer to: its working set is L2-resident (traffic < algorithmic bytes) and its VALU issue "
+                                       "fraction (`valu.frac`) is the larger one",
                          "step": {"algorithmic_bytes_per_step": alg_bytes_step, "achieved": alg_bytes_step / step_s / 1e9,
                                   "unit": "GB/s", "frac": alg_bytes_step / step_s / 1e9 / HBM_PEAK_GBS}},
             "kernels_ms": {"assoc": assoc_ms, "fit": timing_all.ms_fit / max(timing_all.launches_fit, 1), "solve": solve_ms,
