@@ -82,7 +82,7 @@ class GpuBackend:
         return self.capi.Grid(self.mapper, 3.0, 0.2), self.capi.Grid(self.mapper, 3.0, 0.4)   # laser_mapping.cc:44-45,60-68
 
 
-def run(backend, world, poses_true, verbose=False, maps_out=None):
+def run(backend, world, poses_true, verbose=False, maps_out=None, scans=None):
     # a backend may bring its own Rigid3d algebra (the oracle-driven loop of the tests uses the oracle's quaternion forms)
     compose_ = getattr(backend, "compose", compose)
     inverse_ = getattr(backend, "inverse", inverse)
@@ -95,7 +95,7 @@ def run(backend, world, poses_true, verbose=False, maps_out=None):
     last = None
     est, t_stage = [], dict(extract=0.0, odometry=0.0, voxel=0.0, surround=0.0, mapping=0.0, insert=0.0)
     for k in range(n):
-        pts, ring = synth.make_scan(world, poses_true[k], synth.SEED + 5000 + k)
+        pts, ring = scans[k] if scans is not None else synth.make_scan(world, poses_true[k], synth.SEED + 5000 + k)
         t0 = time.perf_counter(); f = backend.extract(pts, ring); t1 = time.perf_counter()
         if last is not None:
             curr2last = backend.scan2scan(last, f, curr2last)                 # laser_odometry.cc:75 (guess = last delta)

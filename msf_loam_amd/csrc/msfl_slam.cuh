@@ -103,4 +103,85 @@ __global__ void slam_map_gate_kernel(const int* __restrict__ n_map_c, const int*
   *status = s;
 }
 
+// ---- voxel filter of ONE list of more than 65 535 points (a 64-beam less-flat list), device-sized --------------------
+// The one-workgroup forms address a run's first point with 16 bits; a longer list is filtered here the plain way:
+// pcl::VoxelGrid's (bounding-box relative) voxel index per point -> stable radix sort of (index, arrival number) ->
+// one centroid per index run, f32 sums in arrival order.  Every kernel acts only when the list was refused (flag 4) and
+// sizes itself from the device-side count; the host enqueues the chain when the scan capacity allows such a list at all.
+struct VoxBigDesc { int mn[3]; int d[3]; int n; int active; };
+
+__global__ void __launch_bounds__(1024)
+vox_big_bbox_kernel(const float4* __restrict__ pts, const int* __restrict__ idx, const int* __restrict__ count, int n_cap, float inv_leaf,
+                    int* __restrict__ flag, int* __restrict__ m_out, VoxBigDesc* __restrict__ desc) {
+  __shared__ int s_mn[3], s_mx[3], s_bad;
+  const int tid = threadIdx.x;
+  const bool active = *flag == 4;
+  if (!active) { if (tid == 0) desc->active = 0; return; }
+  const int n = min(max(*count, 0), n_cap);
+  if (tid == 0) { for (int a = 0; a < 3; a++) { s_mn[a] = INT32_MAX; s_mx[a] = INT32_MIN; } s_bad = 0; }
+  __syncthreads();
+  int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN}, bad = 0;
+  for (int k = tid; k < n; k += 1024) {
+    const float4 p = pts[idx ? idx[k] : k];
+    const float f0 = floorf(p.x * inv_leaf), f1 = floorf(p.y * inv_leaf), f2 = floorf(p.z * inv_leaf);
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { bad = 3; continue; }
+    if (!(fabsf(f0) < 1e9f && fabsf(f1) < 1e9f && fabsf(f2) < 1e9f)) { bad = max(bad, 1); continue; }
+    const int c[3] = {(int)f0, (int)f1, (int)f2};
+    for (int a = 0; a < 3; a++) { mn[a] = min(mn[a], c[a]); mx[a] = max(mx[a], c[a]); }
+  }
+  for (int a = 0; a < 3; a++) { atomicMin(&s_mn[a], mn[a]); atomicMax(&s_mx[a], mx[a]); }
+  if (bad) atomicMax(&s_bad, bad);
+  __syncthreads();
+  if (tid == 0) {
+    int f = s_bad;
+    long long cells = 1;
+    for (int a = 0; a < 3 && !f; a++) { cells *= (long long)s_mx[a] - s_mn[a] + 1; if (cells > 0x7fffffffLL) f = 1; }   // pcl: leaf too small
+    for (int a = 0; a < 3; a++) { desc->mn[a] = s_mn[a]; desc->d[a] = s_mx[a] - s_mn[a] + 1; }
+    desc->n = n;
+    desc->active = (f == 0 && n > 0) ? 1 : 0;
+    if (f != 0 || n == 0) { *flag = f; *m_out = 0; }           // refused for good (non-finite point, leaf too small) or empty
+  }
+}
+
+__global__ void __launch_bounds__(256)
+vox_big_key_kernel(const float4* __restrict__ pts, const int* __restrict__ idx, int n_cap, float inv_leaf, const VoxBigDesc* __restrict__ desc,
+                   unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_cap || !desc->active) return;
+  vals[k] = (unsigned)k;
+  if (k >= desc->n) { keys[k] = 0xffffffffu; return; }
+  const float4 p = pts[idx ? idx[k] : k];
+  const long long i0 = (long long)(int)floorf(p.x * inv_leaf) - desc->mn[0], i1 = (long long)(int)floorf(p.y * inv_leaf) - desc->mn[1],
+                  i2 = (long long)(int)floorf(p.z * inv_leaf) - desc->mn[2];
+  keys[k] = (unsigned)(i0 + i1 * desc->d[0] + i2 * (long long)desc->d[0] * desc->d[1]);
+}
+
+__global__ void __launch_bounds__(256)
+vox_big_head_kernel(const unsigned* __restrict__ skeys, int n_cap, const VoxBigDesc* __restrict__ desc, int* __restrict__ head) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_cap) return;
+  head[k] = (desc->active && k < desc->n && (k == 0 || skeys[k] != skeys[k - 1])) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+vox_big_centroid_kernel(const float4* __restrict__ pts, const int* __restrict__ idx, const unsigned* __restrict__ skeys,
+                        const unsigned* __restrict__ svals, const int* __restrict__ head, const int* __restrict__ pos, int n_cap,
+                        const VoxBigDesc* __restrict__ desc, float4* __restrict__ out, int* __restrict__ m_out, int* __restrict__ flag) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (!desc->active) return;
+  const int n = desc->n;
+  if (k == n - 1) { *m_out = pos[k]; *flag = 0; }
+  if (k >= n || !head[k]) return;
+  const unsigned key = skeys[k];
+  float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+  int j = k;
+  for (; j < n && skeys[j] == key; j++) {
+    const int a = (int)svals[j];
+    const float4 p = pts[idx ? idx[a] : a];
+    sx += p.x; sy += p.y; sz += p.z; sw += p.w;                  // CentroidPoint accumulators (f32), arrival order (stable sort)
+  }
+  const float c = (float)(j - k);
+  out[pos[k] - 1] = make_float4(sx / c, sy / c, sz / c, sw / c);
+}
+
 }  // namespace msfl

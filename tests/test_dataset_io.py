@@ -154,3 +154,34 @@ def test_kitti_layout_replays_through_the_pipeline(gpu, oracle, tmp_path):
     log.save(path)
     back = dataset.PoseLog.load(path)
     assert all(np.array_equal(a[1], b) for a, b in zip(back.odom, est))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beams", [16, 64])
+def test_kitti_layout_replays_through_the_device_resident_slam_step(oracle, tmp_path, beams):
+    """A sequence written in KITTI layout (velodyne/*.bin without ring ids, times.txt, poses), read back through
+    dataset.KittiSequence (rings re-derived from elevation) and fed to msfl_slam_add_scan scan by scan: the poses must
+    equal the oracle-driven odometry + mapping loop on the same clouds.  64 beams: a ~100 k-point less-flat list is beyond
+    what the one-workgroup voxel filter and the scan-to-scan column grid address (65 535 points), so this also covers the
+    point-sort voxel form and the brute-force association of the SLAM step."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import replay_synthetic as rp
+    from tests.test_gpu_replay import OracleBackendRigid3d
+    n = 12 if beams == 16 else 5
+    world = synth.World(ground_half=45.0)
+    truth = rp.trajectory(300)[:n]
+    kw = dict(n_beams=64, n_az=1900, elev=(-24.8, 2.0)) if beams == 64 else {}
+    clouds = [synth.make_scan(world, truth[k], synth.SEED + 7000 + k, **kw)[0] for k in range(n)]
+    dataset.write_kitti_sequence(str(tmp_path), "07", clouds, 0.1 * np.arange(n), poses_lidar=truth)
+    seq = dataset.KittiSequence(str(tmp_path), "07")
+    ring_kw = dict(n_scans=64, low_deg=-24.8, high_deg=2.0) if beams == 64 else dict(n_scans=16, low_deg=-15.0, high_deg=15.0)
+    scans = [seq.scan(i, **ring_kw) for i in range(len(seq))]
+    assert len(scans) == n and all(int(r.max()) == beams - 1 for _, r in scans)
+    est_o, _ = rp.run(OracleBackendRigid3d(oracle), world, truth, scans=scans)
+    for pipelined in (False, True):
+        est_g, recs, _ = rp.run_slam(world, truth, pipelined=pipelined, scans=scans)
+        assert all(r.status_extract == 0 for r in recs) and all(r.status_mapping == 0 for r in recs[1:]), [(r.status_extract, r.status_mapping) for r in recs]
+        d = np.array([synth.pose_error(a, b) for a, b in zip(est_g, est_o)])
+        assert d[:, 0].max() < 1e-6 and d[:, 1].max() < 1e-6, (beams, pipelined, d.max(axis=0))
+    assert dataset.ate_rmse(est_g, seq.ground_truth, align=False) < 0.3
