@@ -371,4 +371,61 @@ class HybridGrid {
   msfl_grid* g_ = nullptr;
 };
 
+// LaserOdometry + LaserMapping as one device-resident pipeline (msfl_slam_*): the raw cloud of
+// RealHandleLaserCloudMessage (msf_loam_node.cc:160-167) in, pose_scan2world_ (laser_odometry.cc:79) and
+// pose_map_scan2world_ (laser_mapping.cc:304-311) out; the feature clouds, the two surrounded map clouds, both HybridGrids
+// and the pose chain never leave the GPU.  LiDAR-only branch (estimator not initialised).
+class LaserSlam {
+ public:
+  struct Poses { Rigid3d odom, map; bool mapped; int scan_index; };
+
+  explicit LaserSlam(int device = 0, int max_scan_points = 200000, int max_rings = 128, const Rigid3d& pose_odom2map = Rigid3d::Identity()) {
+    msfl_slam_config c;
+    msfl_slam_default_config(&c);
+    c.max_scan_points = max_scan_points; c.max_rings = max_rings;
+    const auto v = pose_odom2map.ToVector7();
+    for (int k = 0; k < 7; ++k) c.pose_odom2map[k] = v[k];
+    const msfl_status st = msfl_slam_create(nullptr, &c, device, &s_);
+    if (st != MSFL_OK) throw std::runtime_error(std::string("msfl_slam_create: ") + msfl_status_string(st));
+  }
+  ~LaserSlam() { msfl_slam_destroy(s_); }
+  LaserSlam(const LaserSlam&) = delete;
+  LaserSlam& operator=(const LaserSlam&) = delete;
+
+  // LaserOdometry::AddLaserScan + one LaserMapping::Run iteration; waits for this scan's mapping result.
+  // `mapped` is false when the map gate (laser_mapping.cc:284-285) kept MatchScan2Map from running.
+  Poses AddLaserScan(const PointCloud<PointTypeOriginal>& laser_cloud_in) {
+    Enqueue(laser_cloud_in, &rec_);
+    return Unpack(rec_);
+  }
+  // The two-thread form: enqueue scan k (returns its index at once), fetch results one scan late with Result(k - 1); the
+  // odometry chain of scan k then runs under the mapping chain of scan k - 1.
+  int AddLaserScanAsync(const PointCloud<PointTypeOriginal>& laser_cloud_in) { Enqueue(laser_cloud_in, nullptr); return n_ - 1; }
+  Poses Result(int scan_index) {
+    const msfl_status st = msfl_slam_get_result(s_, scan_index, &rec_);
+    if (st != MSFL_OK) throw std::runtime_error(std::string("msfl_slam_get_result: ") + msfl_status_string(st) + " " + msfl_slam_last_error(s_));
+    return Unpack(rec_);
+  }
+  const msfl_slam_result& last_record() const { return rec_; }
+
+ private:
+  void Enqueue(const PointCloud<PointTypeOriginal>& in, msfl_slam_result* out) {
+    std::vector<msfl_point> p; std::vector<std::uint16_t> r;
+    detail::Pack(in, &p, &r);
+    const msfl_status st = msfl_slam_add_scan(s_, p.data(), r.data(), static_cast<int>(p.size()), MSFL_MEM_HOST, out);
+    if (st != MSFL_OK) throw std::runtime_error(std::string("msfl_slam_add_scan: ") + msfl_status_string(st) + " " + msfl_slam_last_error(s_));
+    ++n_;
+  }
+  static Poses Unpack(const msfl_slam_result& r) {
+    if (r.status_extract != MSFL_OK)          // the reference CHECK-aborts on these (msf_loam_node.cc:136,186,200)
+      throw std::runtime_error(std::string("feature extraction: ") + msfl_status_string(r.status_extract));
+    std::array<double, 7> o, m;
+    for (int k = 0; k < 7; ++k) { o[k] = r.pose_odom[k]; m[k] = r.pose_map[k]; }
+    return Poses{Rigid3d(o), Rigid3d(m), r.status_mapping == MSFL_OK, r.scan_index};
+  }
+  msfl_slam* s_ = nullptr;
+  msfl_slam_result rec_{};
+  int n_ = 0;
+};
+
 }  // namespace msfl

@@ -15,7 +15,9 @@
 namespace msfl {
 
 // counts block of one scan, written by the extraction kernels: [n_full, n_sharp, n_less_sharp, n_flat, n_less_flat, status, -, -]
-enum { SC_FULL = 0, SC_SHARP, SC_LESS_SHARP, SC_FLAT, SC_LESS_FLAT, SC_STATUS, SC_OVERFLOW, SC_WORDS = 8 };
+enum { SC_FULL = 0, SC_SHARP, SC_LESS_SHARP, SC_FLAT, SC_LESS_FLAT, SC_STATUS, SC_OVERFLOW, SC_USE_LS, SC_USE_LF, SC_WORDS = 12 };
+// SC_USE_LS / SC_USE_LF: the less-sharp / less-flat counts the mapping thread works with: the extraction's, or 0 for a scan that is
+// not processed (failed extraction, a list beyond the launch bounds), so that such a scan is neither matched nor inserted
 
 struct SlamCaps { int sharp, less_sharp, flat, less_flat; };     // host-side bounds the launches are sized for
 
@@ -44,6 +46,8 @@ slam_gather_kernel(const float4* __restrict__ full, const uint16_t* __restrict__
     const int over = ok && (cnt[SC_SHARP] > caps.sharp || cnt[SC_LESS_SHARP] > caps.less_sharp || cnt[SC_FLAT] > caps.flat ||
                             cnt[SC_LESS_FLAT] > caps.less_flat) ? 1 : 0;
     cnt[SC_OVERFLOW] = over;
+    cnt[SC_USE_LS] = (ok && !over) ? n_ls : 0;
+    cnt[SC_USE_LF] = (ok && !over) ? n_lf : 0;
     *odo_status = (!ok || over) ? 3 /*MSFL_BAD_ARG: a scan without features is not matched*/ : 0;
   }
   if (list == 0) { if (i < n_sharp) sharp_pts[i] = full[sharp_idx[i]]; }

@@ -5,6 +5,7 @@
 //   out: 7 f64 map pose | 7 f64 odom pose | i32 odom_ok | i32 n_sharp n_less_sharp n_flat n_less_flat
 //        | 7 f64 map pose of the reference-signature (8-argument) call, is_initialized = false
 //        | 7 f64 map pose of the 8-argument call, is_initialized = true (deskew branch)
+//        | 3 x (7 f64 odometry pose, 7 f64 map pose) of LaserSlam fed the same cloud three times
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -75,6 +76,14 @@ int main(int argc, char** argv) {
     *vel_j = msfl::Vector3d{{vel_in[0], vel_in[1], vel_in[2]}};
   });
   const bool ok8d = mapper.MatchScan2Map(map, cur, true, pre, gravity, prev, &pose8d, &vel8d) && hook_calls == 1;
+  // the whole per-scan loop: the same cloud three times (synchronous, then the two-thread form)
+  msfl::LaserSlam slam(0, n, 16, msfl::Rigid3d(std::array<double, 7>{{guess[0], guess[1], guess[2], guess[3], guess[4], guess[5], guess[6]}}));
+  const auto s0 = slam.AddLaserScan(cloud);
+  const int k1 = slam.AddLaserScanAsync(cloud);
+  const int k2 = slam.AddLaserScanAsync(cloud);
+  const auto s1 = slam.Result(k1);
+  const auto s2 = slam.Result(k2);
+  const bool slam_ok = !s0.mapped && s1.mapped && s2.mapped && s0.scan_index == 0 && s1.scan_index == 1 && s2.scan_index == 2;
   FILE* o = fopen(argv[2], "wb");
   auto v = pose.ToVector7(); auto w = rel.ToVector7();
   fwrite(v.data(), 8, 7, o); fwrite(w.data(), 8, 7, o);
@@ -83,6 +92,7 @@ int main(int argc, char** argv) {
   fwrite(ints, 4, 5, o);
   auto v8 = pose8.ToVector7(); auto v8d = pose8d.ToVector7();
   fwrite(v8.data(), 8, 7, o); fwrite(v8d.data(), 8, 7, o);
+  for (const auto* sp : {&s0, &s1, &s2}) { auto a = sp->odom.ToVector7(), b = sp->map.ToVector7(); fwrite(a.data(), 8, 7, o); fwrite(b.data(), 8, 7, o); }
   fclose(o);
-  return (ok && ok8 && ok8d) ? 0 : 3;
+  return (ok && ok8 && ok8d && slam_ok) ? 0 : 3;
 }

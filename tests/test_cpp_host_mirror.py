@@ -31,7 +31,7 @@ def test_header_is_plain_c_and_links():
     exe = os.path.join(ROOT, "tests", "cpp", "c_header_check")
     assert os.path.exists(exe)
     out = subprocess.check_output([exe]).decode()         # pure host calls: default params, API version, symbol addresses
-    assert "21 entry points" in out and "sizeof(msfl_point)=16" in out
+    assert "26 entry points" in out and "sizeof(msfl_point)=16" in out and "sizeof(msfl_slam_result)=480" in out
 
 
 @pytest.mark.gpu
@@ -74,3 +74,12 @@ def test_cpp_host_mirror_matches_ctypes_path(gpu, tmp_path):
     s, pose_d, _ = gpu.match_scan2map_deskew(corner, surf, cdq, cdp, sdq, sdp, vel, grav, guess)
     assert s == 0 and np.array_equal(pose8d, pose_d)
     assert not np.array_equal(pose8d, pose8)
+    # LaserSlam (msfl_slam_* behind the reference's AddLaserScan shape) == the ctypes binding on the same three scans
+    from msf_loam_amd import capi
+    sl = capi.Slam(0, max_scan_points=len(pts), max_rings=16, pose_odom2map=guess)
+    recs = [sl.add_scan(pts, ring) for _ in range(3)]
+    sl.close()
+    for k, r in enumerate(recs):
+        o = 244 + 112 * k
+        assert np.array_equal(np.frombuffer(raw[o:o + 56], "<f8"), np.array(r.pose_odom[:])), k
+        assert np.array_equal(np.frombuffer(raw[o + 56:o + 112], "<f8"), np.array(r.pose_map[:])), k
