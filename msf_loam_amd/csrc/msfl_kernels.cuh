@@ -716,7 +716,10 @@ struct EdgeList {
 #ifdef MSFL_LM_PROFILE
 __device__ unsigned long long g_lm_prof[8];   // cycles (lane 0, summed over workgroups): eval, reduce, serial, total, passes
 #define LM_T(x) const unsigned long long x = wall_clock64()
-#define LM_ADD(k, v) if (threadIdx.x == 0) atomicAdd(&g_lm_prof[k], (unsigned long long)(v))
+#ifndef MSFL_LM_PROFILE_BLOCK
+#define MSFL_LM_PROFILE_BLOCK 0      /* 0: every instantiation; else only the one with this many threads */
+#endif
+#define LM_ADD(k, v) if (threadIdx.x == 0 && (MSFL_LM_PROFILE_BLOCK == 0 || MSFL_LM_PROFILE_BLOCK == (int)blockDim.x)) atomicAdd(&g_lm_prof[k], (unsigned long long)(v))
 #else
 #define LM_T(x)
 #define LM_ADD(k, v)
