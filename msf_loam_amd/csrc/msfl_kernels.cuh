@@ -538,6 +538,99 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   }
 }
 
+// K4a, latency form: the same exact 5-NN for a launch too small to fill the machine (one scan per call: ~5 000 queries are
+// 80 wavefronts on 1 024 SIMDs, and a query is a chain of up to nine dependent row-bound -> candidate load round trips,
+// ~35 us).  Sixteen lanes serve one query: lane r < 9 owns row r of the 3 x 3 (y, z) neighbourhood, reads its two row
+// bounds and scans its candidates into a private top-5 against the acceptance gate only (rows are not pruned against
+// each other: that would serialise them again), then the nine sorted lists are merged by five rounds of "smallest head
+// of the group".  Keys are (distance bits, map index), so the five survivors and their order are exactly those of
+// knn5_grid: an exact top-5 does not depend on the visit order.  Lanes 0..4 translate and store one neighbour each.
+constexpr int kKnnRowLanes = 16;
+constexpr int kKnnRowsBlock = 256;
+#ifndef MSFL_KNN_ROWS_MAX
+#define MSFL_KNN_ROWS_MAX 32768
+#endif
+constexpr int kKnnRowsMaxRecords = MSFL_KNN_ROWS_MAX;   // launches of up to this many queries take the latency form (measured crossover: DESIGN.md)
+__global__ void __launch_bounds__(kKnnRowsBlock)
+knn5_scan2map_rows_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
+                          const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
+                          const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
+                          const int* __restrict__ pos_c, const int* __restrict__ pos_s, float max_sq_dist, int* __restrict__ nn) {
+  const int sl = threadIdx.x & (kKnnRowLanes - 1);
+  const int g = bv.rec_begin + (int)((blockIdx.x * kKnnRowsBlock + threadIdx.x) / kKnnRowLanes);
+  if (g >= batch_records(bv)) return;                         // whole groups leave together
+  const int b = find_scan(bv.rec_off, bv.n_scans, g);
+  int* out = nn + 5 * (size_t)g;
+  if (status[b] != 0) { if (sl < 5) out[sl] = -1; return; }
+  const int local = g - bv.rec_off[b];
+  const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
+  const bool is_edge = local < nc;
+  const int fi = is_edge ? bv.corner_off[b] + local : bv.surf_off[b] + (local - nc);
+  const float4 f = is_edge ? bv.corner[fi] : bv.surf[fi];
+  const pose7 T = load_pose(poses + 7 * b);
+  const float3 q = transform_point_f32(T, f.x, f.y, f.z);    // :123 / :193
+  const GridDesc gd = is_edge ? *gcp : *gsp;
+  const float4* __restrict__ sorted = is_edge ? map_c : map_s;
+  const int* __restrict__ cell_start = is_edge ? cs_c : cs_s;
+  Top5 t;
+  top5_init(t, max_sq_dist);
+  const unsigned long long sentinel = t.k0;
+  const float ux = (q.x - gd.ox) * gd.inv_cell_x, uy = (q.y - gd.oy) * gd.inv_cell, uz = (q.z - gd.oz) * gd.inv_cell;
+  const int cx = grid_coord(q.x, gd.ox, gd.inv_cell_x, gd.dx);
+  const int cy = grid_coord(q.y, gd.oy, gd.inv_cell, gd.dy);
+  const int cz = grid_coord(q.z, gd.oz, gd.inv_cell, gd.dz);
+  const int xs = max(cx - kGridXSub, 0), xe = min(cx + kGridXSub, gd.dx - 1);
+  const int y = cy + (sl % 3) - 1, z = cz + (sl / 3) - 1;
+  if (sl < 9 && xs <= xe && y >= 0 && y < gd.dy && z >= 0 && z < gd.dz) {
+    const float gy = axis_gap(uy, y), gz = axis_gap(uz, z);
+    const float row2 = (gy * gy + gz * gz) * gd.cell2;
+    if (!(row2 > max_sq_dist)) {
+      // end cells whose lower bound is beyond the gate hold no acceptable candidate
+      int a = xs, e_cell = xe;
+      bool da = true, db = true;
+#pragma unroll
+      for (int k = 0; k < kGridXSub; k++) {
+        const float ga = axis_gap(ux, xs + k), gb = axis_gap(ux, xe - k);
+        da = da && (row2 + ga * ga * gd.cellx2 > max_sq_dist); a += da ? 1 : 0;
+        db = db && (row2 + gb * gb * gd.cellx2 > max_sq_dist); e_cell -= db ? 1 : 0;
+      }
+      if (a <= e_cell) {
+        const int row = (z * gd.dy + y) * gd.dx;
+        const int s = cell_start[row + a], e = cell_start[row + e_cell + 1];
+        const msfl_f2 qxy = {q.x, q.y};
+        for (int i = s; i < e; i += 4) {                    // four loads requested together (clamped index)
+          float4 m[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { m[u] = sorted[min(i + u, e - 1)]; asm volatile("" : "+v"(m[u].w)); }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (i + u < e) top5_insert(t, l2_simple_pk(m[u], qxy, q.z), __float_as_int(m[u].w));
+        }
+      }
+    }
+  }
+  // merge: five times the smallest head of the group's (sorted) lists; the owner pops.  Map indices are unique, so
+  // real keys are too; equal heads are sentinels, and popping a sentinel list changes nothing.
+  unsigned long long best[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    unsigned long long m = t.k0;
+#pragma unroll
+    for (int o = kKnnRowLanes / 2; o > 0; o >>= 1) {
+      const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)m, o, kKnnRowLanes), hi = (unsigned)__shfl_xor((int)(unsigned)(m >> 32), o, kKnnRowLanes);
+      const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+      m = other < m ? other : m;
+    }
+    best[j] = m;
+    if (t.k0 == m) { t.k0 = t.k1; t.k1 = t.k2; t.k2 = t.k3; t.k3 = t.k4; t.k4 = sentinel; }
+  }
+  if (sl >= 5) return;
+  const bool accepted = (unsigned int)best[4] != 0xffffffffu && (double)__uint_as_float((unsigned int)(best[4] >> 32)) < (double)max_sq_dist;   // :128 / :198
+  const unsigned long long mine = sl == 0 ? best[0] : sl == 1 ? best[1] : sl == 2 ? best[2] : sl == 3 ? best[3] : best[4];
+  const int* po = is_edge ? pos_c : pos_s;
+  out[sl] = accepted ? po[(unsigned int)mine] : -1;           // nearest first
+}
+
 // K4b: 5 neighbours -> line fit (3x3 Jacobi eigen) / plane fit (5x3 Householder QR) -> record.
 // Edge: {C, N}.  Plane: {N, N.C} (the residual N.(Rp+t-C) only needs the offset N.C).
 // `full` (optional, debug/parity API) receives {C, N} for every feature.
@@ -628,6 +721,7 @@ struct DevMatchInfo {   // mirrors msfl_match_info
 };
 
 constexpr int kAcc = 28;   // cost + g[6] + H upper[21]
+static_assert(kAcc + 2 == 30, "block_reduce folds 30 values");
 
 // ---- robustified normal equations, one residual row at a time ----------------------------------------------
 // Ceres scales residual and Jacobian of a block by sqrt(rho') (Corrector with rho'' <= 0) and then forms
@@ -826,6 +920,33 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   // trips ahead, branch-free (0.249 / 0.258 / 0.264 vs 0.233 ms: more bytes in flight do not help a bandwidth-bound
   // pass); solving the batch in 2 / 4 launches of fewer scans (0.41 / 0.71 ms: with fewer resident workgroups the
   // pass becomes latency bound instead).
+  // One solve per launch (BLOCK = 512, the SLAM step): the machine is empty and a pass is a chain of dependent load round
+  // trips, ten of them in the FILL pass.  Four trips' loads are requested together (clamped index, no branch around them);
+  // the rows are still accumulated in ascending i per thread, so the sums are those of the plain loop bit for bit.
+  constexpr int kGroup = BLOCK >= 512 ? 4 : 1;
+  if (kGroup > 1 && use_cache) {
+    for (; i < ns; i += kGroup * BLOCK) {
+      double gn[kGroup][4];
+      float4 gf[kGroup];
+#pragma unroll
+      for (int u = 0; u < kGroup; u++) {
+        const int iu = min(i + u * BLOCK, ns - 1);
+        const double* r4 = recp + 4 * (size_t)iu;
+        gn[u][0] = r4[0]; gn[u][1] = r4[1]; gn[u][2] = r4[2]; gn[u][3] = r4[3];
+        gf[u] = surf[iu];
+      }
+#pragma unroll
+      for (int u = 0; u < kGroup; u++) {
+        const int iu = i + u * BLOCK;
+        if (iu >= ns) break;
+        if (FILL && iu < PlaneCache<BLOCK>::kPlanes) {
+          pc.nx[iu] = gn[u][0]; pc.ny[iu] = gn[u][1]; pc.nz[iu] = gn[u][2]; pc.d0[iu] = gn[u][3];
+          pc.px[iu] = gf[u].x; pc.py[iu] = gf[u].y; pc.pz[iu] = gf[u].z;
+        }
+        plane_row(mk3(gn[u][0], gn[u][1], gn[u][2]), gn[u][3], mk3((double)gf[u].x, (double)gf[u].y, (double)gf[u].z));
+      }
+    }
+  }
   for (; i < ns; i += BLOCK) {
     const double* r4 = recp + 4 * (size_t)i;
     const d3 N = mk3(r4[0], r4[1], r4[2]); const double d0 = r4[3];
@@ -856,41 +977,61 @@ struct TrState {
 
 template <int BLOCK>
 struct LmShared {
-  double part[BLOCK / 64][kAcc];
+  double part[BLOCK / 64][kAcc + 2];   // per wavefront: {cost, g, H} and the two correspondence counts (as doubles: exact)
   double red[kAcc];          // reduced {cost, g, H} of the last pass
-  int    cnt_part[BLOCK / 64][2];
   int    cnt[2];
   TrState tr;
   int    go;                 // 1: evaluate candidate, 0: finished
 };
 
-// deterministic block reduction: butterfly inside the wave, fixed order across waves
+// deterministic block reduction, fixed order inside the wave and across waves.  Inside the wave the 30 values are not
+// reduced one butterfly each (30 x 6 exchanges): every exchange step halves the number of values a lane carries — at
+// offset 32 the lower half-wave keeps values 0..14 and receives the upper half's share of them while the upper half keeps
+// 15..29, and so on down to one value per lane pair: 15 + 8 + 4 + 2 + 1 + 1 = 31 exchanges.  The lane whose bits say
+// (b5 b4 b3 b2 b1) ends up with value 15 b5 + 8 b4 + 4 b3 + 2 b2 + b1 (slot 15 of each half is padding).
 template <int BLOCK>
 __device__ __forceinline__ void block_reduce(LmShared<BLOCK>& sh, double (&acc)[kAcc], int n_edge, int n_plane) {
-#pragma unroll
-  for (int k = 0; k < kAcc; k++) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { n_edge += __shfl_xor(n_edge, o); n_plane += __shfl_xor(n_plane, o); }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) {
+  double v16[16], v8[8], v4[4], v2[2], x;
+  {
+    const bool up = lane & 32;
 #pragma unroll
-    for (int k = 0; k < kAcc; k++) sh.part[wave][k] = acc[k];
-    sh.cnt_part[wave][0] = n_edge; sh.cnt_part[wave][1] = n_plane;
+    for (int k = 0; k < 15; k++) {
+      const double a = acc[k < kAcc ? k : 0];
+      const double b = k + 15 < kAcc ? acc[k + 15 < kAcc ? k + 15 : 0] : (k + 15 == kAcc ? (double)n_edge : (double)n_plane);
+      v16[k] = (up ? b : a) + __shfl_xor(up ? a : b, 32);
+    }
+    v16[15] = 0.0;
   }
+  {
+    const bool up = lane & 16;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v8[k] = (up ? v16[k + 8] : v16[k]) + __shfl_xor(up ? v16[k] : v16[k + 8], 16);
+  }
+  {
+    const bool up = lane & 8;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v4[k] = (up ? v8[k + 4] : v8[k]) + __shfl_xor(up ? v8[k] : v8[k + 4], 8);
+  }
+  {
+    const bool up = lane & 4;
+#pragma unroll
+    for (int k = 0; k < 2; k++) v2[k] = (up ? v4[k + 2] : v4[k]) + __shfl_xor(up ? v4[k] : v4[k + 2], 4);
+  }
+  {
+    const bool up = lane & 2;
+    x = (up ? v2[1] : v2[0]) + __shfl_xor(up ? v2[0] : v2[1], 2);
+  }
+  x += __shfl_xor(x, 1);
+  const int slot = (lane >> 1) & 15;
+  if (!(lane & 1) && slot != 15) sh.part[wave][15 * (lane >> 5) + slot] = x;
   __syncthreads();
-  if (threadIdx.x < kAcc) {
+  if (threadIdx.x < kAcc + 2) {
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < BLOCK / 64; w++) s += sh.part[w][threadIdx.x];
-    sh.red[threadIdx.x] = s;
-  } else if (threadIdx.x < kAcc + 2) {
-    int s = 0;
-#pragma unroll
-    for (int w = 0; w < BLOCK / 64; w++) s += sh.cnt_part[w][threadIdx.x - kAcc];
-    sh.cnt[threadIdx.x - kAcc] = s;
+    if (threadIdx.x < kAcc) sh.red[threadIdx.x] = s;
+    else sh.cnt[threadIdx.x - kAcc] = (int)s;
   }
   // no barrier here: the sums are written and then read (trust-region logic, lane 0) inside wavefront 0, in program
   // order; every other reader comes after the barrier that ends the serial section

@@ -393,3 +393,43 @@ def test_candidate_counter_mode_counts_and_keeps_results(gpu):
     assert t.launches_assoc == 2
     assert 5 * n_query * 0.5 < t.knn_candidates < 2000 * n_query       # at least ~5 per accepted query, far below the map size
     assert h.get_timing(reset=False).knn_candidates == 0                 # reset
+
+
+def test_both_forms_of_the_5nn_search_agree_bit_for_bit(oracle, monkeypatch):
+    """Launches of up to 32 768 queries take the row-parallel latency form of the 5-NN kernel (sixteen lanes per query, one
+    lane per (y, z) row, five-round merge), larger ones the one-lane-per-query form.  An exact top-5 over (distance,
+    index) keys does not depend on the visit order: records, poses and iteration counts must be equal bit for bit, on
+    the lattice map (ties, duplicates, gate boundaries) and on scans."""
+    from msf_loam_amd import capi
+    hs = {}
+    for form in ("lane", "rows"):
+        monkeypatch.setenv("MSFL_KNN_FORM", form)
+        hs[form] = capi.Handle(0)
+    monkeypatch.delenv("MSFL_KNN_FORM")
+    try:
+        _, mc, ms = common.small_world()
+        for h in hs.values():
+            h.set_map(mc, ms)
+        n_acc = 0
+        for pts, ring, truth, guess in common.scans(4):
+            _, corner, surf = common.features_from_oracle(oracle, pts, ring)
+            rec = {f: h.associate_scan2map(corner, surf, guess) for f, h in hs.items()}
+            assert np.array_equal(rec["lane"], rec["rows"])
+            n_acc += int(np.any(rec["rows"][:, 3:] != 0, axis=1).sum())
+            out = {f: h.match_scan2map(corner, surf, guess) for f, h in hs.items()}
+            assert np.array_equal(out["lane"][1], out["rows"][1])
+            assert list(out["lane"][2].lm_iterations) == list(out["rows"][2].lm_iterations)
+        assert n_acc > 4000
+        # sparse and empty neighbourhoods, queries outside the index's bounding box, a map of five points
+        rng = np.random.default_rng(5)
+        tiny = np.concatenate([rng.uniform(-2, 2, (5, 3)), np.zeros((5, 1))], 1).astype(np.float32)
+        cloud = np.concatenate([rng.uniform(-30, 30, (3000, 3)), np.zeros((3000, 1))], 1).astype(np.float32)
+        far = np.concatenate([rng.uniform(-80, 80, (500, 3)), np.zeros((500, 1))], 1).astype(np.float32)
+        for m_c, m_s in ((tiny, cloud), (cloud[:700], tiny), (cloud[:40], cloud)):
+            for h in hs.values():
+                h.set_map(m_c, m_s)
+            rec = {f: h.associate_scan2map(far[:100], far, np.array([0.3, -0.2, 0.1, 0, 0, 0, 1.0])) for f, h in hs.items()}
+            assert np.array_equal(rec["lane"], rec["rows"])
+    finally:
+        for h in hs.values():
+            h.close()
