@@ -465,11 +465,7 @@ __device__ __forceinline__ unsigned wave_extremum_u32(unsigned k) {
 constexpr int kPickCand = 8;
 constexpr int kPickSector = 64 * kPickCand;
 
-// FUSED: the ring's wavefront also produces what extract_curvature_kernel produces for the ring's points (curvature, label
-// reset, gap flags — the flags straight into the LDS mask, never to memory) from a 74-point LDS tile per 64 points.
-template <bool FUSED>
 __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView v, ExtractParams prm) {
-  __shared__ float4 s_tile[FUSED ? kExWaves : 1][74];
   __shared__ unsigned int s_picked[kExWaves][kRingCapacity / 32 + 2];
   __shared__ unsigned int s_corner[kExWaves][kRingCapacity / 32 + 2];
   __shared__ unsigned int s_gap[kExWaves][kRingCapacity / 32 + 2];
@@ -488,20 +484,18 @@ __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView
   const int o = __builtin_amdgcn_readfirstlane(v.off[b]);
   int n_sharp = 0, n_ls = 0, n_flat = 0, n_lf = 0;
   const int start = s + 5, end = s + len - 6;                               // :192-194
-  const bool scan_ok = __builtin_amdgcn_readfirstlane(v.status[b]) == 0;
-  const bool active = scan_ok && len > 0 && (end - start >= 6);  // :252
-  const bool fits = len <= kRingCapacity;
-  if (FUSED ? !(scan_ok && len > 0) : !active) {
+  const bool active = (__builtin_amdgcn_readfirstlane(v.status[b]) == 0) && len > 0 && (end - start >= 6);  // :252
+  if (!active) {
     if (lane == 0) { cnt_out[0] = 0; cnt_out[1] = 0; cnt_out[2] = 0; cnt_out[3] = 0; }
     return;
   }
-  if (!FUSED && !fits) {
+  if (len > kRingCapacity) {
     if (lane == 0) { v.status[b] = 7 /*MSFL_CAPACITY*/; cnt_out[0] = cnt_out[1] = cnt_out[2] = cnt_out[3] = 0; }
     return;
   }
   uint8_t* label = v.label + o;
   const uint8_t* gapb = v.gap + o;
-  float* curv = v.curvature + o;
+  const float* curv = v.curvature + o;
   int* t_sharp = v.tmp_idx + 0 * (size_t)v.n_total + o + s;
   int* t_ls = v.tmp_idx + 1 * (size_t)v.n_total + o + s;
   int* t_flat = v.tmp_idx + 2 * (size_t)v.n_total + o + s;
@@ -514,70 +508,17 @@ __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   // ring-local bitmasks: bit k <-> scan-local index s + k
-  const int N = FUSED ? __builtin_amdgcn_readfirstlane(v.n_full[b]) : 0;
-  const float4* pts = v.full_pts + o;
   for (int w0 = 0; w0 < len + 64; w0 += 64) {       // one extra round: the spare words behind the ring
     const int k = w0 + lane;
-    bool gbit;
-    if (FUSED) {
-      // tile[t] = point (s + w0 - 5 + t) of the scan, t < 74: the 64 points of this round and five either side.  Slots outside
-      // the scan stay unread: the margin tests below keep every window inside it.
-      float4* tile = s_tile[wave];
-      const int i0 = s + w0 - 5;
-      if (i0 + lane >= 0 && i0 + lane < N) tile[lane] = pts[i0 + lane];
-      if (lane < 10 && i0 + 64 + lane < N) tile[64 + lane] = pts[i0 + 64 + lane];
-      wave_sync();
-      const int i = s + k;
-      gbit = true;
-      if (k < len && i < N) {
-        const float4* c = tile + lane + 5;                         // c[j] = point i + j of this scan, |j| <= 5
-        float cvv = 0.f;
-        if (i >= 5 && i < N - 5) {
-          // f32 sums in source order (:214-234), f64 squares, f32 store (:236)
-          const float4 m5 = c[-5], m4 = c[-4], m3 = c[-3], m2 = c[-2], m1 = c[-1], p0 = c[0];
-          const float4 p1 = c[1], p2 = c[2], p3 = c[3], p4 = c[4], p5 = c[5];
-          const float dx = m5.x + m4.x + m3.x + m2.x + m1.x - 10 * p0.x + p1.x + p2.x + p3.x + p4.x + p5.x;
-          const float dy = m5.y + m4.y + m3.y + m2.y + m1.y - 10 * p0.y + p1.y + p2.y + p3.y + p4.y + p5.y;
-          const float dz = m5.z + m4.z + m3.z + m2.z + m1.z - 10 * p0.z + p1.z + p2.z + p3.z + p4.z + p5.z;
-          const double X = dx, Y = dy, Z = dz;
-          cvv = (float)(X * X + Y * Y + Z * Z);
-        }
-        curv[i] = cvv;
-        label[i] = 0;
-        if (i + 1 < N) {
-          const float4 a = c[1], q = c[0];
-          const float ex = a.x - q.x, ey = a.y - q.y, ez = a.z - q.z;
-          const float sq = ex * ex + ey * ey + ez * ez;           // Vector3f squaredNorm
-          gbit = (double)sq > prm.neighbor_gap_sq;                  // :293,300,326,332
-        }
-      }
-      wave_sync();                                                  // the next round overwrites the tile
-    } else {
-      gbit = (k < len) ? (gapb[s + k] != 0) : true;
-    }
+    const bool gbit = (k < len) ? (gapb[s + k] != 0) : true;
     const unsigned long long m = __ballot(gbit);
-    if (lane == 0 && (!FUSED || fits)) {
+    if (lane == 0) {
       gap.w[(w0 >> 5)] = (unsigned int)m; gap.w[(w0 >> 5) + 1] = (unsigned int)(m >> 32);
       picked.w[(w0 >> 5)] = 0; picked.w[(w0 >> 5) + 1] = 0;
       corner.w[(w0 >> 5)] = 0; corner.w[(w0 >> 5) + 1] = 0;
     }
   }
-  if (FUSED) {
-    // the curvatures and label resets above are read / overwritten below by other lanes of this wavefront
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (!active) {
-      if (lane == 0) { cnt_out[0] = 0; cnt_out[1] = 0; cnt_out[2] = 0; cnt_out[3] = 0; }
-      return;
-    }
-    if (!fits) {
-      if (lane == 0) { v.status[b] = 7 /*MSFL_CAPACITY*/; cnt_out[0] = cnt_out[1] = cnt_out[2] = cnt_out[3] = 0; }
-      return;
-    }
-  }
   wave_sync();
-  auto load_curv = [&](int idx) __attribute__((always_inline)) -> float {
-    return FUSED ? __hip_atomic_load(curv + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : curv[idx];
-  };
   for (int j = 0; j < prm.sectors; j++) {
     const int sp = start + (end - start) * j / prm.sectors;                 // :256-259
     const int ep = start + (end - start) * (j + 1) / prm.sectors - 1;
@@ -601,7 +542,7 @@ __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView
     };
     if (in_lds) {
 #pragma unroll
-      for (int t = 0; t < kPickCand; t++) cv[t] = load_curv(min(sp + lane + 64 * t, ep));
+      for (int t = 0; t < kPickCand; t++) cv[t] = curv[min(sp + lane + 64 * t, ep)];
       stage(std::true_type{});
     }
     // The arg-max (corner pass) / arg-min (flat pass) of the live candidates as a scan-local position, -1 = none left.
@@ -625,7 +566,7 @@ __global__ void __launch_bounds__(64 * kExWaves) extract_pick_kernel(ExtractView
       }
       unsigned long long best = kCorner ? 0ull : ~0ull;
       for (int pos = sp + lane; pos <= ep; pos += 64) {
-        const float c = load_curv(pos);
+        const float c = curv[pos];
         const bool q = kCorner ? ((double)c > prm.curvature_threshold) : ((double)c < prm.curvature_threshold);
         if (!q || picked.get(pos - s)) continue;
         const unsigned long long key = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned int)pos;
