@@ -132,7 +132,6 @@ struct msfl_handle_s {
   bool voxel_force_global = false;        // MSFL_VOXEL_GLOBAL=1: the batched voxel filter keeps the device-wide radix-sort form (A/B testing)
   long long odom_wave_max_targets = -1;   // MSFL_ODOM_WAVE_MAX_TARGETS: previous-scan points up to which a small batch takes the one-wavefront-per-query kernel (default 4096 per pair)
   bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)
-  bool fuse_fit = false;                  // MSFL_FUSE_FIT=1 (experiment): line / plane fit inside the 5-NN thread
   int knn_form = 0;                       // MSFL_KNN_FORM: 0 auto (row-parallel latency form for launches of <= kKnnRowsMaxRecords queries),
                                           // 1 "lane" (one lane per query always), 2 "rows" (row-parallel always); results are identical
 
@@ -321,14 +320,6 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
                            (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
                            (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
                            h->prm.map_knn_max_sq_dist, dv, nn, cnt);
-    } else if (!deskew && !full && h->fuse_fit) {
-      hipLaunchKernelGGL((knn5_scan2map_kernel<false, false, true>), grid, block, 0, st, bv, d_poses, d_status,
-                         (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
-                         (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
-                         (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
-                         h->prm.map_knn_max_sq_dist, dv, nn, (unsigned long long*)nullptr,
-                         FuseFit{h->prm.line_eigen_ratio, h->prm.plane_tolerance, h->records.as<double>()});
-      return;
     } else if (!deskew && (h->knn_form == 2 || (h->knn_form == 0 && n_rec <= kKnnRowsMaxRecords)))
       hipLaunchKernelGGL(knn5_scan2map_rows_kernel, dim3(div_up(n_rec, kKnnRowsBlock / kKnnRowLanes)), dim3(kKnnRowsBlock), 0, st, bv, d_poses, d_status,
                          (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
@@ -500,7 +491,6 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
   if (const char* e = std::getenv("MSFL_H2D_CHUNK_SCANS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_chunk_scans = c; }
   if (const char* e = std::getenv("MSFL_H2D_SUB_CHUNKS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_sub_chunks = c; }
   if (const char* e = std::getenv("MSFL_ODOM_BRUTE")) h->odom_force_brute = std::atoi(e) != 0;
-  if (const char* e = std::getenv("MSFL_FUSE_FIT")) h->fuse_fit = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSFL_KNN_FORM")) h->knn_form = !std::strcmp(e, "lane") ? 1 : !std::strcmp(e, "rows") ? 2 : 0;
   if (const char* e = std::getenv("MSFL_ODOM_WAVE_MAX_TARGETS")) h->odom_wave_max_targets = std::atoll(e);
   if (const char* e = std::getenv("MSFL_VOXEL_GLOBAL")) h->voxel_force_global = std::atoi(e) != 0;

@@ -477,20 +477,18 @@ struct DeskewView {
 #define MSFL_ASSOC_BLOCK 64
 #endif
 constexpr int kAssocBlock = MSFL_ASSOC_BLOCK;      // threads per workgroup of the 5-NN and fit kernels
-struct FuseFit { double line_ratio, plane_tol; double* rec; };   // FUSE experiment: the fit runs in the 5-NN thread, nn is never written
-template <bool DESKEW, bool COUNT = false, bool FUSE = false>
+template <bool DESKEW, bool COUNT = false>
 __global__ void __launch_bounds__(kAssocBlock)
 knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
                      const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
                      const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
                      const int* __restrict__ pos_c, const int* __restrict__ pos_s,
-                     float max_sq_dist, DeskewView dv, int* __restrict__ nn, unsigned long long* __restrict__ n_candidates = nullptr,
-                     FuseFit ff = FuseFit{}) {
+                     float max_sq_dist, DeskewView dv, int* __restrict__ nn, unsigned long long* __restrict__ n_candidates = nullptr) {
   const int g = bv.rec_begin + blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= batch_records(bv)) return;
   const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);
   int* out = nn + 5 * (size_t)g;
-  if (!FUSE && status[b] != 0) { out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1; return; }
+  if (status[b] != 0) { out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1; return; }
   const int local = g - bv.rec_off[b];
   const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
   const bool is_edge = local < nc;
@@ -528,25 +526,6 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
     int tot = 0;
     while (m) { const int l = __ffsll((long long)m) - 1; tot += __shfl(n_cand, l); m &= m - 1; }
     if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(n_candidates, (unsigned long long)tot);
-  }
-  if (FUSE) {
-    const bool have = (unsigned int)t.k4 != 0xffffffffu && (double)top5_d4(t) < (double)max_sq_dist;
-    FitOut fo; fo.ok = false; fo.C = mk3(0, 0, 0); fo.N = mk3(0, 0, 0);
-    const int* po = is_edge ? pos_c : pos_s;
-    const float4* mp = is_edge ? map_c : map_s;
-    const unsigned i0 = have ? (unsigned int)t.k0 : 0u, i1 = have ? (unsigned int)t.k1 : 0u, i2 = have ? (unsigned int)t.k2 : 0u,
-                   i3 = have ? (unsigned int)t.k3 : 0u, i4 = have ? (unsigned int)t.k4 : 0u;
-    const int q0 = po[i0], q1 = po[i1], q2 = po[i2], q3 = po[i3], q4 = po[i4];
-    const float4 nb[5] = {mp[q0], mp[q1], mp[q2], mp[q3], mp[q4]};
-    if (have) fo = is_edge ? edge_fit(nb, ff.line_ratio) : plane_fit(nb, ff.plane_tol);
-    if (is_edge) {
-      double* o = ff.rec + edge_rec_off(bv, bv.corner_off[b] + local);
-      o[0] = fo.C.x; o[1] = fo.C.y; o[2] = fo.C.z; o[3] = fo.N.x; o[4] = fo.N.y; o[5] = fo.N.z;
-    } else {
-      double* o = ff.rec + plane_rec_off(bv, bv.surf_off[b] + (local - nc));
-      o[0] = fo.N.x; o[1] = fo.N.y; o[2] = fo.N.z; o[3] = dot(fo.N, fo.C);
-    }
-    return;
   }
   if ((unsigned int)t.k4 != 0xffffffffu && (double)top5_d4(t) < (double)max_sq_dist) {      // :128 / :198
     // original map index -> position in the sorted map array (the fit kernel then gathers directly);
