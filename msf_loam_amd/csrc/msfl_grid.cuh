@@ -97,6 +97,20 @@ __device__ __forceinline__ int grid_dev_n(int n_cap, const int* __restrict__ n_d
 
 // (the per-insert fields of GridState are left zeroed by grid_finish_kernel, so an insert needs no reset launch)
 
+// (cell key << 21 | voxel inside the cell) of a point, kGridBadKey when the cell or the voxel is out of range
+__device__ __forceinline__ unsigned long long grid_point_key(float4 p, const GridStoreDesc& d) {
+  const int ix = grid_cell_index(p.x, d.resolution), iy = grid_cell_index(p.y, d.resolution), iz = grid_cell_index(p.z, d.resolution);
+  unsigned long long key = grid_cell_key(ix, iy, iz);
+  if (key != kGridBadKey) {
+    const int rx = grid_vox_rel(p.x, ix, d), ry = grid_vox_rel(p.y, iy, d), rz = grid_vox_rel(p.z, iz, d);
+    const int lim = 1 << kGridVoxBits;
+    if (rx < 0 || rx >= lim || ry < 0 || ry >= lim || rz < 0 || rz >= lim) key = kGridBadKey;
+    else key = (key << (3 * kGridVoxBits)) | ((unsigned long long)rz << (2 * kGridVoxBits)) | ((unsigned long long)ry << kGridVoxBits) |
+               (unsigned long long)rx;
+  }
+  return key;
+}
+
 // ---- insert, step 1: (optional) rigid transform + 63-bit key of every new point -------------------------------------
 // pose != null: p <- TransformPoint(pose, p) (laser_mapping.cc:24-31 / rigid_transform.h:131-137: f32 -> f64 -> q p + t -> f32),
 // written to xf (what the rest of the insert reads); pose == null: xf is not touched and the caller passes pts as xf.
@@ -116,15 +130,7 @@ grid_key_kernel(const float4* __restrict__ pts, int n_cap, const int* __restrict
     p = make_float4(q.x, q.y, q.z, p.w);
     xf[i] = p;
   }
-  const int ix = grid_cell_index(p.x, d.resolution), iy = grid_cell_index(p.y, d.resolution), iz = grid_cell_index(p.z, d.resolution);
-  unsigned long long key = grid_cell_key(ix, iy, iz);
-  if (key != kGridBadKey) {
-    const int rx = grid_vox_rel(p.x, ix, d), ry = grid_vox_rel(p.y, iy, d), rz = grid_vox_rel(p.z, iz, d);
-    const int lim = 1 << kGridVoxBits;
-    if (rx < 0 || rx >= lim || ry < 0 || ry >= lim || rz < 0 || rz >= lim) key = kGridBadKey;
-    else key = (key << (3 * kGridVoxBits)) | ((unsigned long long)rz << (2 * kGridVoxBits)) | ((unsigned long long)ry << kGridVoxBits) |
-               (unsigned long long)rx;
-  }
+  const unsigned long long key = grid_point_key(p, d);
   if (key == kGridBadKey) st->bad = 1;              // a non-finite coordinate lands here too (lround of NaN / inf is out of range)
   keys[i] = key;
 }
@@ -157,6 +163,118 @@ grid_touch_list_kernel(const unsigned long long* __restrict__ skeys, const int* 
   if (i >= n || dropped) return;
   if (head[i]) { const int t = tpos[i] - 1; t_key[t] = skeys[i] >> (3 * kGridVoxBits); t_ns[t] = i; }
   if (i == n - 1) { st->n_touched = tpos[i]; t_ns[tpos[i]] = n; }
+}
+
+// ---- one-workgroup forms for the per-scan SLAM step ------------------------------------------------------------------------
+// A scan's insert / surround works on tens of thousands of keys and hundreds of cells: the parallel primitives (a device-wide
+// scan is two launches and a host-side planning call) cost more in launches than in work.  These kernels do the same job in
+// one 1 024-thread workgroup; results are the same integers.  (Not the kNN index's cell table: a one-workgroup scan of its
+// ~100 k counters measured 71 us against the device-wide scan's 9.)
+
+// inclusive scan of one int per thread over the workgroup (1 024 threads); returns the inclusive value, total = workgroup sum
+__device__ __forceinline__ int block_incl_scan_1024(int t, int* s_wave /* [16] */, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = t;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int pre = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) { const int x = s_wave[w]; tot += x; pre += w < wave ? x : 0; }
+  __syncthreads();                                      // s_wave is written again by the caller's next round
+  total = tot;
+  return incl + pre;
+}
+
+// insert, steps 2 + 3 in one launch (grid_touch_flag_kernel, the inclusive scan of the heads, grid_touch_list_kernel)
+__global__ void __launch_bounds__(1024)
+grid_touch_kernel(const unsigned long long* __restrict__ skeys, int n_cap, const int* __restrict__ n_dev, unsigned long long* __restrict__ t_key,
+                  int* __restrict__ t_ns, GridState* __restrict__ st) {
+  __shared__ int s_wave[16];
+  const int n = grid_dev_n(n_cap, n_dev);
+  if (n == 0 || st->bad != 0) {                       // a dropped insert (bad point) touches nothing
+    if (threadIdx.x == 0) { st->n_touched = 0; t_ns[0] = 0; }
+    return;
+  }
+  int carry = 0;
+  for (int base = 0; base < n; base += 4 * 1024) {
+    const int i0 = base + 4 * (int)threadIdx.x;
+    unsigned long long c[5];
+#pragma unroll
+    for (int u = 0; u < 5; u++) { const int i = i0 - 1 + u; c[u] = (i >= 0 && i < n) ? skeys[i] >> (3 * kGridVoxBits) : ~0ull; }
+    int h[4], t = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { h[u] = (i0 + u < n && (i0 + u == 0 || c[u + 1] != c[u])) ? 1 : 0; t += h[u]; }
+    int total;
+    int run = carry + block_incl_scan_1024(t, s_wave, total) - t;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (h[u]) { t_key[run] = c[u + 1]; t_ns[run] = i0 + u; run++; }
+    carry += total;
+  }
+  if (threadIdx.x == 0) { st->n_touched = carry; t_ns[carry] = n; }
+}
+
+// surround, per-cell emit counts + their exclusive scan in one launch (grid_emit_count_kernel + the device-wide scan)
+__global__ void __launch_bounds__(1024)
+grid_emit_scan_kernel(const int* __restrict__ stamp, const int* __restrict__ cell_cnt, int bound, int* __restrict__ cnt, int* __restrict__ off,
+                      const GridState* __restrict__ st) {
+  __shared__ int s_wave[16];
+  const int n_cells = st->n_cells, epoch = st->epoch;
+  bound = min(bound, n_cells);                          // grid_emit_kernel reads neither array beyond the live cells
+  int carry = 0;
+  for (int base = 0; base < bound; base += 4 * 1024) {
+    const int c0 = base + 4 * (int)threadIdx.x;
+    int v[4], t = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int c = c0 + u; v[u] = (c < bound && c < n_cells && stamp[c] == epoch) ? cell_cnt[c] : 0; t += v[u]; }
+    int total;
+    int run = carry + block_incl_scan_1024(t, s_wave, total) - t;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int c = c0 + u; if (c < bound) { cnt[c] = v[u]; off[c] = run; } run += v[u]; }
+    carry += total;
+  }
+}
+
+// insert, step 1 + the stable sort for a list of at most 2 048 points (the corner side of a scan): keys as grid_key_kernel
+// makes them, then a bitonic sort in LDS of (key, ordinal) — the ordinal as the tie-break is what a stable sort gives.
+constexpr int kGridSortSmall = 2048;
+constexpr int kGridOneBlockMax = 1 << 17;          // lists / cell tables up to this size take the one-workgroup forms
+__global__ void __launch_bounds__(1024)
+grid_key_sort_small_kernel(const float4* __restrict__ pts, int n_cap, const int* __restrict__ n_dev, const double* __restrict__ pose,
+                           float4* __restrict__ xf, GridStoreDesc d, unsigned long long* __restrict__ skeys, int* __restrict__ svals,
+                           GridState* __restrict__ st) {
+  __shared__ unsigned long long s_key[kGridSortSmall];
+  __shared__ unsigned short s_val[kGridSortSmall];
+  const int n = grid_dev_n(n_cap, n_dev);
+  for (int i = threadIdx.x; i < kGridSortSmall; i += 1024) {
+    unsigned long long key = kGridBadKey;
+    if (i < n) {
+      float4 p = pts[i];
+      if (pose) {
+        const float3 q = transform_point_f32(load_pose(pose), p.x, p.y, p.z);
+        p = make_float4(q.x, q.y, q.z, p.w);
+        xf[i] = p;
+      }
+      key = grid_point_key(p, d);
+      if (key == kGridBadKey) st->bad = 1;
+    }
+    s_key[i] = key; s_val[i] = (unsigned short)i;
+  }
+  __syncthreads();
+  for (int k = 2; k <= kGridSortSmall; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int t = threadIdx.x;                                   // 1 024 compare-exchanges per stage
+      const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+      const bool up = (lo & k) == 0;
+      const unsigned long long ka = s_key[lo], kb = s_key[hi];
+      const unsigned short va = s_val[lo], vb = s_val[hi];
+      const bool a_after_b = ka > kb || (ka == kb && va > vb);
+      if (a_after_b == up) { s_key[lo] = kb; s_key[hi] = ka; s_val[lo] = vb; s_val[hi] = va; }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < n_cap; i += 1024) { skeys[i] = s_key[i]; svals[i] = (int)s_val[i]; }
 }
 
 __device__ __forceinline__ int grid_find_cell(const unsigned long long* __restrict__ cell_keys, int n_cells, unsigned long long key) {
