@@ -132,12 +132,6 @@ struct msfl_handle_s {
   bool voxel_force_global = false;        // MSFL_VOXEL_GLOBAL=1: the batched voxel filter keeps the device-wide radix-sort form (A/B testing)
   long long odom_wave_max_targets = -1;   // MSFL_ODOM_WAVE_MAX_TARGETS: previous-scan points up to which a small batch takes the one-wavefront-per-query kernel (default 4096 per pair)
   bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)
-  // Large device-resident batches are registered as `batch_split` sub-batches on streams of their own, each one fit kernel behind
-  // its predecessor: the bandwidth- / latency-bound solve of one sub-batch runs under the issue-bound 5-NN and fit kernels of the
-  // next (MSFL_BATCH_SPLIT, 1 = off).  Per-scan results do not depend on it.
-  int batch_split = MSFL_BATCH_SPLIT_DEFAULT;
-  hipStream_t aux_stream[kMaxBatchSplit - 1] = {};
-  hipEvent_t ev_split_start = nullptr, ev_split_fit[kMaxBatchSplit] = {}, ev_split_done[kMaxBatchSplit] = {};
   int knn_form = 0;                       // MSFL_KNN_FORM: 0 auto (row-parallel latency form for launches of <= kKnnRowsMaxRecords queries),
                                           // 1 "lane" (one lane per query always), 2 "rows" (row-parallel always); results are identical
 
@@ -303,8 +297,8 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi, 
 // one data-association pass = kNN kernel + fit kernel
 // (records [rec_begin, rec_end) of the batch; rec_end < 0: all of them)
 void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_poses, const int* d_status, bool deskew,
-                    const DeskewView& dv, int n_rec, double* full = nullptr, int rec_begin = 0, int rec_end = -1, hipStream_t on = nullptr) {
-  hipStream_t st = on ? on : h->stream;
+                    const DeskewView& dv, int n_rec, double* full = nullptr, int rec_begin = 0, int rec_end = -1) {
+  hipStream_t st = h->stream;
   int* nn = h->nn.as<int>();
   BatchView bv = bv_all;
   if (rec_end >= 0) { bv.rec_begin = rec_begin; bv.n_records = rec_end; n_rec = rec_end - rec_begin; }
@@ -393,38 +387,6 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
     dv.pprime = h->pprime.as<double>();
   }
   const SolverParams sp = solver_params(h->prm, 0);
-  const int S = (n_chunks == 1 && !enqueue_chunk && h->timing == 0 && B >= kBatchSplitMinScans) ? std::min(h->batch_split, kMaxBatchSplit) : 1;
-  if (S > 1 && n_rec > 0) {
-    if (!h->ev_split_start) {
-      HIPCHK(h, hipEventCreateWithFlags(&h->ev_split_start, hipEventDisableTiming));
-      for (auto& e : h->ev_split_fit) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      for (auto& e : h->ev_split_done) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    for (int j = 0; j + 1 < S; j++) if (!h->aux_stream[j]) HIPCHK(h, hipStreamCreateWithFlags(&h->aux_stream[j], hipStreamNonBlocking));
-    auto stream_of = [&](int j) { return j == 0 ? st : h->aux_stream[j - 1]; };
-    const int* rec_off_h = offs.data() + 2 * (size_t)(B + 1);
-    HIPCHK(h, hipEventRecord(h->ev_split_start, st));                  // offsets, index, poses: everything enqueued so far
-    for (int j = 1; j < S; j++) HIPCHK(h, hipStreamWaitEvent(stream_of(j), h->ev_split_start, 0));
-    for (int it = 0; it < h->prm.outer_iterations; it++)
-      for (int j = 0; j < S; j++) {
-        const int b0 = (int)((long long)B * j / S), b1 = (int)((long long)B * (j + 1) / S);
-        hipStream_t sj = stream_of(j);
-        if (it == 0 && j > 0) HIPCHK(h, hipStreamWaitEvent(sj, h->ev_split_fit[j - 1], 0));   // the stagger
-        s_launch_assoc(h, bv, d_poses, d_status, deskew != nullptr, dv, n_rec, nullptr, rec_off_h[b0], rec_off_h[b1], sj);
-        if (it == 0 && j + 1 < S) HIPCHK(h, hipEventRecord(h->ev_split_fit[j], sj));
-        BatchView bj = bv;
-        bj.scan_begin = b0;
-        hipLaunchKernelGGL(lm_solve_kernel<kLmBlock>, dim3(b1 - b0), dim3(kLmBlock), 0, sj, bj,
-                           deskew ? (const double*)dv.pprime : (const double*)nullptr,
-                           (const double*)h->records.as<double>(), d_poses, d_status, d_info, it, sp);
-      }
-    for (int j = 1; j < S; j++) {
-      HIPCHK(h, hipEventRecord(h->ev_split_done[j], stream_of(j)));
-      HIPCHK(h, hipStreamWaitEvent(st, h->ev_split_done[j], 0));
-    }
-    HIPCHK(h, hipGetLastError());
-    return MSFL_OK;
-  }
   for (int it = 0; it < h->prm.outer_iterations; it++) {
     if (it == 0 && (n_chunks > 1 || enqueue_chunk)) {
       for (int c = 0; c < n_chunks; c++) {
@@ -529,7 +491,6 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
   if (const char* e = std::getenv("MSFL_H2D_CHUNK_SCANS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_chunk_scans = c; }
   if (const char* e = std::getenv("MSFL_H2D_SUB_CHUNKS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_sub_chunks = c; }
   if (const char* e = std::getenv("MSFL_ODOM_BRUTE")) h->odom_force_brute = std::atoi(e) != 0;
-  if (const char* e = std::getenv("MSFL_BATCH_SPLIT")) h->batch_split = std::min(std::max(std::atoi(e), 1), kMaxBatchSplit);
   if (const char* e = std::getenv("MSFL_KNN_FORM")) h->knn_form = !std::strcmp(e, "lane") ? 1 : !std::strcmp(e, "rows") ? 2 : 0;
   if (const char* e = std::getenv("MSFL_ODOM_WAVE_MAX_TARGETS")) h->odom_wave_max_targets = std::atoll(e);
   if (const char* e = std::getenv("MSFL_VOXEL_GLOBAL")) h->voxel_force_global = std::atoi(e) != 0;
@@ -572,10 +533,6 @@ void msfl_destroy(msfl_handle* h) {
   for (auto& b : h->pp) b.release();
   for (auto& b : h->vb) b.release();
   for (auto& b : h->vb2) b.release();
-  for (auto a : h->aux_stream) if (a) (void)hipStreamDestroy(a);
-  if (h->ev_split_start) (void)hipEventDestroy(h->ev_split_start);
-  for (auto e : h->ev_split_fit) if (e) (void)hipEventDestroy(e);
-  for (auto e : h->ev_split_done) if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }

@@ -427,7 +427,6 @@ struct BatchView {
   int rec_begin = 0;        // association kernels: first record of this launch (a host-buffer batch is associated chunk by chunk as it arrives)
   int c0, s0;               // corner_off[0], surf_off[0] (host copies)
   int n_surf_total;         // surf_off[n_scans] - surf_off[0]
-  int scan_begin = 0;       // solve kernel: first scan of this launch (a large batch is solved in sub-batches on streams of their own)
   int dyn = 0;              // 1: the offsets were written on the device (per-scan SLAM step); n_records is then an upper bound and the
                             // record count is rec_off[n_scans]; c0 = s0 = 0 and n_surf_total is the surf cloud's CAPACITY (a layout constant)
 };
@@ -762,11 +761,6 @@ __device__ __forceinline__ void huber_weight(double a, double s, double abs_r, d
 #ifndef MSFL_LM_BLOCK
 #define MSFL_LM_BLOCK 128
 #endif
-#ifndef MSFL_BATCH_SPLIT_DEFAULT
-#define MSFL_BATCH_SPLIT_DEFAULT 1
-#endif
-constexpr int kMaxBatchSplit = 4;            // sub-batches (= streams) of one large registration batch
-constexpr int kBatchSplitMinScans = 256;     // smaller batches stay one launch set
 constexpr int kLmBlock = MSFL_LM_BLOCK;                        // threads per scan in the scan-to-map LM solve
 #ifndef MSFL_ODOM_LM_BLOCK
 #define MSFL_ODOM_LM_BLOCK 128
@@ -1274,7 +1268,7 @@ lm_solve_kernel(BatchView bv, const double* __restrict__ pprime_all, const doubl
   __shared__ LmShared<BLOCK> sh;
   __shared__ PlaneCache<BLOCK> s_cache;
   __shared__ EdgeList s_edges;
-  const int b = bv.scan_begin + blockIdx.x;
+  const int b = blockIdx.x;
   if (status[b] != 0) return;
   if (threadIdx.x < kEdgeListMax / 32) s_edges.mask[threadIdx.x] = 0;
   __syncthreads();
