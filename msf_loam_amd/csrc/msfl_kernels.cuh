@@ -778,6 +778,14 @@ constexpr int kOdomLmBlock = MSFL_ODOM_LM_BLOCK;               // scan-to-scan: 
 constexpr int lm_edge_cache(int block) { return block == 256 ? MSFL_LM_EDGE_CACHE : 0; }      // 60 B each
 // 512 threads: the one-solve-per-call SLAM step, where the machine is empty and a solve is as long as its chain of passes
 // (3 072 planes x 44 B = 132 KB, one workgroup per CU)
+// trips of the streamed plane loop whose loads are requested together (see evaluate_pass): 512 threads have <= 10 trips in all
+#ifndef MSFL_LM_GROUP_SMALL
+#define MSFL_LM_GROUP_SMALL 8
+#endif
+#ifndef MSFL_LM_GROUP_LARGE
+#define MSFL_LM_GROUP_LARGE 4
+#endif
+constexpr int lm_load_group(int block) { return block >= 512 ? MSFL_LM_GROUP_LARGE : MSFL_LM_GROUP_SMALL; }
 constexpr int lm_plane_cache(int block) {
 #ifdef MSFL_LM_PLANE_CACHE
   return block == 256 ? MSFL_LM_PLANE_CACHE : block == 128 ? 832 : block == 512 ? 3072 : 384;
@@ -839,28 +847,8 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   // FILL: every edge, accepted ones marked; later passes: the dense list first, then the unlisted tail
   const int n_listed = FILL ? 0 : el.n;
   const int n_walk = FILL ? nc : n_listed + max(nc - kEdgeListMax, 0);
-  for (int k = threadIdx.x; k < n_walk; k += BLOCK) {
-    const bool listed = !FILL && k < n_listed;
-    const int i = FILL ? k : (listed ? (int)el.idx[k] : kEdgeListMax + (k - n_listed));
-    d3 C, N, p;
-    if (!FILL && pprime == nullptr && i < PlaneCache<BLOCK>::kEdges) {
-      C = mk3(pc.ecx[i], pc.ecy[i], pc.ecz[i]); N = mk3(pc.enx[i], pc.eny[i], pc.enz[i]);
-      p = mk3((double)pc.epx[i], (double)pc.epy[i], (double)pc.epz[i]);
-    } else {
-      const double* r6 = rec + 6 * (size_t)i;
-      C = mk3(r6[0], r6[1], r6[2]);
-      N = mk3(r6[3], r6[4], r6[5]);
-      if (pprime) p = mk3(pprime[3 * (size_t)i], pprime[3 * (size_t)i + 1], pprime[3 * (size_t)i + 2]);
-      else {
-        const float4 f = corner[i];                              // curr_point: untransformed (:146)
-        p = mk3((double)f.x, (double)f.y, (double)f.z);
-        if (FILL && i < PlaneCache<BLOCK>::kEdges) {
-          pc.ecx[i] = C.x; pc.ecy[i] = C.y; pc.ecz[i] = C.z; pc.enx[i] = N.x; pc.eny[i] = N.y; pc.enz[i] = N.z;
-          pc.epx[i] = f.x; pc.epy[i] = f.y; pc.epz[i] = f.z;
-        }
-      }
-    }
-    if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) continue;      // rejected correspondence (never a listed one)
+  auto edge_row = [&](int i, d3 C, d3 N, d3 p) __attribute__((always_inline)) {
+    if (N.x == 0.0 && N.y == 0.0 && N.z == 0.0) return;        // rejected correspondence (never a listed one)
     if (FILL && i < kEdgeListMax) atomicOr(&el.mask[i >> 5], 1u << (i & 31));
     n_edge++;
     // d = R p + t - C through the rotation matrix (the quaternion sandwich costs three times the instructions; the two agree
@@ -889,6 +877,29 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
     acc_row_w(acc, j0, r.x, w);
     acc_row_w(acc, j1, r.y, w);
     acc_row_w(acc, j2, r.z, w);
+  };
+  for (int k = threadIdx.x; k < n_walk; k += BLOCK) {
+    const bool listed = !FILL && k < n_listed;
+    const int i = FILL ? k : (listed ? (int)el.idx[k] : kEdgeListMax + (k - n_listed));
+    d3 C, N, p;
+    if (!FILL && pprime == nullptr && i < PlaneCache<BLOCK>::kEdges) {
+      C = mk3(pc.ecx[i], pc.ecy[i], pc.ecz[i]); N = mk3(pc.enx[i], pc.eny[i], pc.enz[i]);
+      p = mk3((double)pc.epx[i], (double)pc.epy[i], (double)pc.epz[i]);
+    } else {
+      const double* r6 = rec + 6 * (size_t)i;
+      C = mk3(r6[0], r6[1], r6[2]);
+      N = mk3(r6[3], r6[4], r6[5]);
+      if (pprime) p = mk3(pprime[3 * (size_t)i], pprime[3 * (size_t)i + 1], pprime[3 * (size_t)i + 2]);
+      else {
+        const float4 f = corner[i];                              // curr_point: untransformed (:146)
+        p = mk3((double)f.x, (double)f.y, (double)f.z);
+        if (FILL && i < PlaneCache<BLOCK>::kEdges) {
+          pc.ecx[i] = C.x; pc.ecy[i] = C.y; pc.ecz[i] = C.z; pc.enx[i] = N.x; pc.eny[i] = N.y; pc.enz[i] = N.z;
+          pc.epx[i] = f.x; pc.epy[i] = f.y; pc.epz[i] = f.z;
+        }
+      }
+    }
+    edge_row(i, C, N, p);
   }
   LM_T(t_edges_done);
   // planes: {N, N.C}, r = N.(R p + t) - N.C                                    lidar_factor.cc:32
@@ -915,15 +926,14 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
     for (; i < min(ns, PlaneCache<BLOCK>::kPlanes); i += BLOCK)
       plane_row(mk3(pc.nx[i], pc.ny[i], pc.nz[i]), pc.d0[i], mk3((double)pc.px[i], (double)pc.py[i], (double)pc.pz[i]));
   }
-  // (b) the streamed rest (everything in the FILL pass).  The solve is bound by these re-reads: ~1 GB per launch at
-  // ~4.4 TB/s with all 1 024 solves resident (PMC r02).  Measured and rejected: software pipelining the loads 1 / 2 / 3
-  // trips ahead, branch-free (0.249 / 0.258 / 0.264 vs 0.233 ms: more bytes in flight do not help a bandwidth-bound
-  // pass); solving the batch in 2 / 4 launches of fewer scans (0.41 / 0.71 ms: with fewer resident workgroups the
-  // pass becomes latency bound instead).
-  // One solve per launch (BLOCK = 512, the SLAM step): the machine is empty and a pass is a chain of dependent load round
-  // trips, ten of them in the FILL pass.  Four trips' loads are requested together (clamped index, no branch around them);
-  // the rows are still accumulated in ascending i per thread, so the sums are those of the plain loop bit for bit.
-  constexpr int kGroup = BLOCK >= 512 ? 4 : 1;
+  // (b) the streamed rest (everything in the FILL pass): ~1 GB per launch with all 1 024 solves resident (PMC r02).  A thread's
+  // trips are a chain of dependent load round trips at two wavefronts per SIMD, so the loads of kGroup trips are requested
+  // together (clamped index, no branch around them) and the rows then accumulated in ascending i as before: the sums are those
+  // of the plain loop bit for bit.  Measured on the bench batch: 0.227 ms per launch ungrouped, 0.221 / 0.202 / 0.190 / 0.186 with
+  // 2 / 4 / 6 / 8 trips per group (248 VGPRs, no spills).  Measured and rejected earlier: software pipelining the loads 1 / 2 / 3
+  // trips ahead across the loop's back edge (0.249 / 0.258 / 0.264 ms); solving the batch in 2 / 4 launches of fewer scans
+  // (0.41 / 0.71 ms: a launch takes ~0.2 ms however few problems it holds).
+  constexpr int kGroup = lm_load_group(BLOCK);
   if (kGroup > 1 && use_cache) {
     for (; i < ns; i += kGroup * BLOCK) {
       double gn[kGroup][4];
