@@ -479,9 +479,10 @@ msfl_status msfl_grid_dump(msfl_grid* g, msfl_point* out, int capacity, int* n_o
 /* Raw points in, poses out: every intermediate (features, down-sampled clouds, the surrounded    */
 /* map clouds, their kNN index, the two HybridGrid stores, the pose chain) stays in HBM, all        */
 /* sizes are read by the kernels from device memory, and nothing synchronises with the host        */
-/* between the upload of the scan and the 600-byte result record.  Like the reference's two        */
+/* between the upload of the scan and the 480-byte result record.  Like the reference's two        */
 /* threads, the odometry chain of scan k+1 (one HIP stream) overlaps the mapping chain of scan k   */
-/* (another stream) when the caller does not wait for every result.                                */
+/* (another stream; its corner side and the two voxel filters run on two more) when the caller     */
+/* does not wait for every result.                                                                 */
 /* ------------------------------------------------------------------------------------------ */
 
 typedef struct msfl_slam_s msfl_slam;
@@ -516,7 +517,7 @@ typedef struct msfl_slam_result {
 
 void msfl_slam_default_config(msfl_slam_config* c);
 
-/* One SLAM pipeline = the reference's LaserOdometry + LaserMapping pair (two streams, two matchers' scratch, two map stores). */
+/* One SLAM pipeline = the reference's LaserOdometry + LaserMapping pair (four streams, the matchers' scratch, two map stores). */
 msfl_status msfl_slam_create(const msfl_params* params, const msfl_slam_config* config, int device, msfl_slam** out);
 void msfl_slam_destroy(msfl_slam* s);
 
