@@ -120,3 +120,22 @@ def test_map_store_compaction_under_the_slam_step_keeps_the_poses():
     finally:
         del os.environ["MSFL_GRID_MIN_POOL"]
     assert np.array_equal(ref, small)
+
+
+def test_launch_bounds_do_not_change_the_result():
+    """Every launch of the step is sized by host-known upper bounds (scan capacity, pick limits per ring count) and reads the
+    real sizes on the device; short lists take one-workgroup forms of the map store's sort / touch-list kernels, long ones the
+    device-wide ones.  A pipeline configured for 128 rings and 200 000 points per scan (the defaults: corner lists of up to
+    15 360 points, every launch several times larger) must give the poses of one configured tightly, bit for bit."""
+    from msf_loam_amd import capi
+    truth, scans = _scans(12)
+    cap = max(len(p) for p, _ in scans)
+    tight = capi.Slam(0, max_scan_points=cap, max_rings=16, pose_odom2map=truth[0])
+    loose = capi.Slam(0, max_scan_points=200000, max_rings=128, pose_odom2map=truth[0])
+    for k, sc in enumerate(scans):
+        a, b = tight.add_scan(*sc), loose.add_scan(*sc)
+        assert np.array_equal(np.array(a.pose_map[:]), np.array(b.pose_map[:])), k
+        assert np.array_equal(np.array(a.pose_odom[:]), np.array(b.pose_odom[:])), k
+        assert (a.n_corner_ds, a.n_surf_ds, a.n_map_corner, a.n_map_surf) == (b.n_corner_ds, b.n_surf_ds, b.n_map_corner, b.n_map_surf)
+        assert list(a.grid_corner)[:3] == list(b.grid_corner)[:3] and list(a.grid_surf)[:3] == list(b.grid_surf)[:3]
+    tight.close(); loose.close()
