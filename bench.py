@@ -176,7 +176,7 @@ def valu_roof(kernel_prefix, launch_ms):
     except OSError:
         return None
     hit = [k for k in pt["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>") and "sq_insts_valu" in pt["kernels"][k]]
-    mk = [k for k in mix["kernels"] if k.replace(" ", "") == kernel_prefix + "<false,false>"] or \
+    mk = [k for k in mix["kernels"] if k.replace(" ", "") in (kernel_prefix + "<false,false>", kernel_prefix + "<false>", kernel_prefix + "<128>")] or \
          [k for k in mix["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>")]
     if not hit or not mk or launch_ms <= 0:
         return None
@@ -189,6 +189,33 @@ def valu_roof(kernel_prefix, launch_ms):
             "simd_clocks_needed": insts * clk, "simd_clocks_available": simd_clocks, "frac": insts * clk / simd_clocks,
             "source": "SQ_INSTS_VALU: %s; mix: profiles/r03_valu_mix.json (static ISA counts); rates: profiles/r03_valu_rate.md; "
                       "clock 2.4 GHz x 256 CUs x 4 SIMDs" % pt["source"].split(" (")[0]}
+
+
+def kernel_roofs(launch_ms, alg_bytes):
+    """Both roofs for each of the step's three kernel classes: {name: {ms, valu_frac, fetched_GBps, ...}}.  `launch_ms`:
+    {kernel name prefix: measured average launch duration}; counters and instruction mixes come from the committed
+    profiles (valid for the profiled workload only).  `fetched` is what the L2 missed ((2 x FETCH_SIZE + WRITE_SIZE) per
+    launch: HBM plus Infinity-Cache hits), not algorithmic bytes."""
+    out = {}
+    for prefix, ms in launch_ms.items():
+        if ms <= 0:
+            continue
+        try:
+            traffic, _ = pmc_traffic(prefix)
+        except KeyError:
+            traffic = None
+        v = valu_roof(prefix, ms)
+        row = {"avg_launch_ms": ms, "valu_frac": None if v is None else v["frac"],
+               "fetched_bytes_per_launch": traffic,
+               "fetched_GBps": None if traffic is None else traffic / (ms * 1e-3) / 1e9,
+               "fetched_frac_of_hbm_peak": None if traffic is None else traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if prefix in alg_bytes:
+            row["algorithmic_bytes_per_launch"] = alg_bytes[prefix]
+            row["algorithmic_GBps"] = alg_bytes[prefix] / (ms * 1e-3) / 1e9
+        fr = [(row["valu_frac"] or 0.0, "valu"), (row["fetched_frac_of_hbm_peak"] or 0.0, "memory (L2 misses)")]
+        row["nearer_roof"] = max(fr)[1]
+        out[prefix] = row
+    return out
 
 
 def host_buffer_rate(h, inp, B, reps=5):
@@ -412,6 +439,11 @@ def main():
                          "bound_note": "achieved / peak / frac are the HBM figures on ALGORITHMIC bytes (SURVEY.md 8d); `bound` names the roof the "
                                        "kernel is nearer to: its working set is L2-resident (traffic < algorithmic bytes) and its VALU issue "
                                        "fraction (`valu.frac`) is the larger one",
+                         "kernels": (kernel_roofs({ASSOC_KERNEL_PREFIX: assoc_ms, "fit_scan2map_kernel": timing_all.ms_fit / max(timing_all.launches_fit, 1),
+                                                   "lm_solve_kernel": solve_ms},
+                                                  {ASSOC_KERNEL_PREFIX: alg_bytes_assoc, "fit_scan2map_kernel": F_total * (5 * 16 + 20 + 40),
+                                                   "lm_solve_kernel": F_total * 48})
+                                     if (B == 1024 and args.map_points == 200000) else None),
                          "step": {"algorithmic_bytes_per_step": alg_bytes_step, "achieved": alg_bytes_step / step_s / 1e9,
                                   "unit": "GB/s", "frac": alg_bytes_step / step_s / 1e9 / HBM_PEAK_GBS}},
             "kernels_ms": {"assoc": assoc_ms, "fit": timing_all.ms_fit / max(timing_all.launches_fit, 1), "solve": solve_ms,

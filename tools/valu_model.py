@@ -34,7 +34,7 @@ def kernels(asm):
         if name is None:
             continue
         t = line.strip()
-        if t.startswith("s_endpgm"):
+        if t.startswith(".Lfunc_end"):                   # not the first s_endpgm: a kernel with an early exit has several
             yield name, body
             name = None
             continue
