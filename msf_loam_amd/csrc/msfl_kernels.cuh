@@ -406,7 +406,14 @@ __device__ __forceinline__ FitOut plane_fit(const float4 (&nb)[5], double tol) {
     c = c + mk3(A[j][0], A[j][1], A[j][2]);
   }
   c = mk3(c.x / 5.0, c.y / 5.0, c.z / 5.0);
-  const d3 n = normalized_rsq(lstsq5x3(A, b));   // note: lstsq5x3 overwrites A, b
+  bool well = false;
+  d3 x = MSFL_IEEE_DIV ? mk3(0, 0, 0) : lstsq5x3_fast(A, b, well);   // overwrites A, b
+  if (!well) {                                     // ill-conditioned or rank-deficient: the reference's pivoted QR decides
+#pragma unroll
+    for (int j = 0; j < 5; j++) { A[j][0] = (double)nb[j].x; A[j][1] = (double)nb[j].y; A[j][2] = (double)nb[j].z; b[j] = -1.0; }
+    x = lstsq5x3(A, b);
+  }
+  const d3 n = normalized_rsq(x);
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 5; j++) {

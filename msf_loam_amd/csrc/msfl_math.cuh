@@ -210,7 +210,7 @@ __device__ __forceinline__ void sym_eigen3_top(const sym3& S, double& ev_mid, do
 // ---------------------------------------------------------------------------------------------
 // 5x3 least squares by column-pivoted Householder QR, all indices compile-time
 // ---------------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool PIVOT = true>
 __device__ __forceinline__ void qr_step(double (&A)[5][3], double (&b)[5], int (&perm)[3], double (&diag)[3],
                                         double& maxpivot) {
 #pragma clang fp contract(fast)   // f64 fits: FMA only changes rounding at 1e-16, far inside the 1e-9 record tolerance
@@ -224,11 +224,13 @@ __device__ __forceinline__ void qr_step(double (&A)[5][3], double (&b)[5], int (
     cn[j] = s;
   }
   int best = K; double bestn = cn[K];
+  if (PIVOT) {
 #pragma unroll
-  for (int j = K + 1; j < 3; j++) if (cn[j] > bestn) { bestn = cn[j]; best = j; }
+    for (int j = K + 1; j < 3; j++) if (cn[j] > bestn) { bestn = cn[j]; best = j; }
+  }
 #pragma unroll
   for (int j = K + 1; j < 3; j++) {
-    if (best == j) {
+    if (PIVOT && best == j) {
 #pragma unroll
       for (int i = 0; i < 5; i++) { const double t = A[i][K]; A[i][K] = A[i][j]; A[i][j] = t; }
       const int t = perm[K]; perm[K] = perm[j]; perm[j] = t;
@@ -302,6 +304,29 @@ __device__ __forceinline__ d3 lstsq5x3(double (&A)[5][3], double (&b)[5]) {
     else x2 = ys[k];
   }
   return mk3(x0, x1, x2);
+}
+
+// The same least-squares solution without column pivoting, for the well-conditioned systems that are the rule (five points of
+// a plane a few tens of metres from the origin: condition number 1e2-1e3).  Pivoting is what Eigen's colPivHouseholderQr does
+// and what decides its rank; it is also a fifth of the fit kernel's instructions (three column norms, a compare chain and
+// fifteen 64-bit selects per step).  `ok` = every |r_kk| above 1e-5 of the largest: the solution then agrees with the pivoted
+// one to ~1e-11 relative (both are backward stable, the difference is cond x eps) and the rank is 3 in both; otherwise the
+// caller runs lstsq5x3 on a fresh copy, so every rank-deficient or ill-conditioned neighbourhood is decided by the
+// reference's algorithm.
+__device__ __forceinline__ d3 lstsq5x3_fast(double (&A)[5][3], double (&b)[5], bool& ok) {
+  int perm[3] = {0, 1, 2};
+  double diag[3] = {0, 0, 0};
+  double maxpivot = 0.0;
+  qr_step<0, false>(A, b, perm, diag, maxpivot);
+  qr_step<1, false>(A, b, perm, diag, maxpivot);
+  qr_step<2, false>(A, b, perm, diag, maxpivot);
+  const double dmin = fmin(fabs(diag[0]), fmin(fabs(diag[1]), fabs(diag[2])));
+  ok = dmin > 1e-5 * maxpivot;                                   // false for NaN too
+  if (!ok) return mk3(0, 0, 0);
+  const double y2 = b[2] * fast_rcp(A[2][2]);
+  const double y1 = (b[1] - A[1][2] * y2) * fast_rcp(A[1][1]);
+  const double y0 = (b[0] - A[0][1] * y1 - A[0][2] * y2) * fast_rcp(A[0][0]);
+  return mk3(y0, y1, y2);
 }
 
 }  // namespace msfl
