@@ -176,11 +176,11 @@ def valu_roof(kernel_prefix, launch_ms):
     except OSError:
         return None
     hit = [k for k in pt["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>") and "sq_insts_valu" in pt["kernels"][k]]
-    mk = [k for k in mix["kernels"] if k.replace(" ", "") in (kernel_prefix + "<false,false>", kernel_prefix + "<false>", kernel_prefix + "<128>")] or \
+    mk = [k for k in mix["kernels"] if k.replace(" ", "") in (kernel_prefix + "<false,false>", kernel_prefix + "<false,2>", kernel_prefix + "<128>")] or \
          [k for k in mix["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>")]
     if not hit or not mk or launch_ms <= 0:
         return None
-    insts = pt["kernels"][hit[0]]["sq_insts_valu"]
+    insts = sum(pt["kernels"][k]["sq_insts_valu"] for k in hit)      # a kernel class launched in several instantiations per pass (the fit's two)
     m = mix["kernels"][mk[0]]
     clk = m["clocks_per_inst_static_mix"]
     simd_clocks = 1024 * 2.4e9 * launch_ms * 1e-3

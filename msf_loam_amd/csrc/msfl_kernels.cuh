@@ -644,18 +644,31 @@ knn5_scan2map_rows_kernel(BatchView bv, const double* __restrict__ poses, const 
 #ifndef MSFL_FIT_WAVES
 #define MSFL_FIT_WAVES 1
 #endif
-template <bool DESKEW>
-__global__ void __launch_bounds__(kAssocBlock, MSFL_FIT_WAVES)
+// KIND 0: every record of [rec_begin, n_records) (one thread each, edges and planes as they come); KIND 1 / 2: the launch covers
+// the batch's corner / surf features only (thread = feature index in its cloud), so that the compiler sees one of the two fits.
+template <bool DESKEW, int KIND = 0>
+__global__ void __launch_bounds__(kAssocBlock, KIND == 2 ? 4 : MSFL_FIT_WAVES)
 fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
                     const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
                     double* __restrict__ rec, double* __restrict__ full) {
-  const int g = bv.rec_begin + blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= batch_records(bv)) return;
+  int g, b, local, nc;
+  if (KIND == 0) {
+    g = bv.rec_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= batch_records(bv)) return;
+    b = find_scan_wave(bv.rec_off, bv.n_scans, g);
+    local = g - bv.rec_off[b];
+    nc = bv.corner_off[b + 1] - bv.corner_off[b];
+  } else {
+    const int* off = KIND == 1 ? bv.corner_off : bv.surf_off;
+    const int f = off[0] + blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= off[bv.n_scans]) return;
+    b = find_scan_wave(off, bv.n_scans, f);
+    nc = bv.corner_off[b + 1] - bv.corner_off[b];
+    local = (KIND == 1 ? 0 : nc) + (f - off[b]);
+    g = bv.rec_off[b] + local;
+  }
   const int* in = nn + 5 * (size_t)g;
-  const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);
-  const int local = g - bv.rec_off[b];
-  const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
-  const bool is_edge = local < nc;
+  const bool is_edge = KIND == 0 ? local < nc : KIND == 1;
   FitOut fo; fo.ok = false; fo.C = mk3(0, 0, 0); fo.N = mk3(0, 0, 0);
   // all five indices at once and the five neighbours unconditionally (index 0 stands in when there is no match): behind the
   // `p0 >= 0` test the loads came as three dependent round trips (first index, the other four, the points)
