@@ -176,7 +176,7 @@ def valu_roof(kernel_prefix, launch_ms):
     except OSError:
         return None
     hit = [k for k in pt["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>") and "sq_insts_valu" in pt["kernels"][k]]
-    mk = [k for k in mix["kernels"] if k.replace(" ", "") in (kernel_prefix + "<false,false>", kernel_prefix + "<false,2>", kernel_prefix + "<128>")] or \
+    mk = [k for k in mix["kernels"] if k.replace(" ", "") in (kernel_prefix + "<false,false>", kernel_prefix + "_split_kernel", kernel_prefix + "<128>")] or \
          [k for k in mix["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>")]
     if not hit or not mk or launch_ms <= 0:
         return None
@@ -439,9 +439,9 @@ def main():
                          "bound_note": "achieved / peak / frac are the HBM figures on ALGORITHMIC bytes (SURVEY.md 8d); `bound` names the roof the "
                                        "kernel is nearer to: its working set is L2-resident (traffic < algorithmic bytes) and its VALU issue "
                                        "fraction (`valu.frac`) is the larger one",
-                         "kernels": (kernel_roofs({ASSOC_KERNEL_PREFIX: assoc_ms, "fit_scan2map_kernel": timing_all.ms_fit / max(timing_all.launches_fit, 1),
+                         "kernels": (kernel_roofs({ASSOC_KERNEL_PREFIX: assoc_ms, "fit_scan2map": timing_all.ms_fit / max(timing_all.launches_fit, 1),
                                                    "lm_solve_kernel": solve_ms},
-                                                  {ASSOC_KERNEL_PREFIX: alg_bytes_assoc, "fit_scan2map_kernel": F_total * (5 * 16 + 20 + 40),
+                                                  {ASSOC_KERNEL_PREFIX: alg_bytes_assoc, "fit_scan2map": F_total * (5 * 16 + 20 + 40),
                                                    "lm_solve_kernel": F_total * 48})
                                      if (B == 1024 and args.map_points == 200000) else None),
                          "step": {"algorithmic_bytes_per_step": alg_bytes_step, "achieved": alg_bytes_step / step_s / 1e9,

@@ -346,17 +346,12 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
                          h->records.as<double>(), full);
     else
       if (!bv.dyn && rec_end < 0 && n_rec >= 65536) {
-        // a whole large batch: the surf and the corner features through one specialised launch each (the plane fit alone fits
-        // four wavefronts per SIMD, the mixed kernel three: 0.133 -> 0.122 ms per pass on the bench batch)
+        // a whole large batch: corner and surf features through their own specialisations of the fit (msfl_kernels.cuh)
         const int n_c = n_rec - bv.n_surf_total, n_s = bv.n_surf_total;
-        if (n_s > 0)
-          hipLaunchKernelGGL((fit_scan2map_kernel<false, 2>), dim3(div_up(n_s, kAssocBlock)), block, 0, st, bv, h->map_c.sorted.as<float4>(),
-                             h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
-                             h->records.as<double>(), full);
-        if (n_c > 0)
-          hipLaunchKernelGGL((fit_scan2map_kernel<false, 1>), dim3(div_up(n_c, kAssocBlock)), block, 0, st, bv, h->map_c.sorted.as<float4>(),
-                             h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
-                             h->records.as<double>(), full);
+        const int edge_blocks = div_up(n_c, kAssocBlock), plane_blocks = div_up(n_s, kAssocBlock);
+        hipLaunchKernelGGL(fit_scan2map_split_kernel, dim3(edge_blocks + plane_blocks), block, 0, st, bv, h->map_c.sorted.as<float4>(),
+                           h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
+                           h->records.as<double>(), full, edge_blocks);
       } else
       hipLaunchKernelGGL(fit_scan2map_kernel<false>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(),
                          h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,

@@ -646,21 +646,20 @@ knn5_scan2map_rows_kernel(BatchView bv, const double* __restrict__ poses, const 
 #endif
 // KIND 0: every record of [rec_begin, n_records) (one thread each, edges and planes as they come); KIND 1 / 2: the launch covers
 // the batch's corner / surf features only (thread = feature index in its cloud), so that the compiler sees one of the two fits.
-template <bool DESKEW, int KIND = 0>
-__global__ void __launch_bounds__(kAssocBlock, KIND == 2 ? 4 : MSFL_FIT_WAVES)
-fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
-                    const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
-                    double* __restrict__ rec, double* __restrict__ full) {
+template <bool DESKEW, int KIND>
+__device__ __forceinline__ void fit_one(const BatchView& bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
+                                        const int* __restrict__ nn, double line_ratio, double plane_tol, const DeskewView& dv,
+                                        double* __restrict__ rec, double* __restrict__ full, int block) {
   int g, b, local, nc;
   if (KIND == 0) {
-    g = bv.rec_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    g = bv.rec_begin + block * blockDim.x + threadIdx.x;
     if (g >= batch_records(bv)) return;
     b = find_scan_wave(bv.rec_off, bv.n_scans, g);
     local = g - bv.rec_off[b];
     nc = bv.corner_off[b + 1] - bv.corner_off[b];
   } else {
     const int* off = KIND == 1 ? bv.corner_off : bv.surf_off;
-    const int f = off[0] + blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = off[0] + block * blockDim.x + threadIdx.x;
     if (f >= off[bv.n_scans]) return;
     b = find_scan_wave(off, bv.n_scans, f);
     nc = bv.corner_off[b + 1] - bv.corner_off[b];
@@ -699,6 +698,25 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
     double* o = full + 6 * (size_t)g;
     o[0] = fo.C.x; o[1] = fo.C.y; o[2] = fo.C.z; o[3] = fo.N.x; o[4] = fo.N.y; o[5] = fo.N.z;
   }
+}
+
+template <bool DESKEW>
+__global__ void __launch_bounds__(kAssocBlock, MSFL_FIT_WAVES)
+fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
+                    const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
+                    double* __restrict__ rec, double* __restrict__ full) {
+  fit_one<DESKEW, 0>(bv, map_c, map_s, nn, line_ratio, plane_tol, dv, rec, full, (int)blockIdx.x);
+}
+// A whole large batch (plain branch): blocks [0, edge_blocks) fit the corner features, the rest the surf features, each
+// through its own specialisation of the body, at four wavefronts per SIMD (the plane fit alone needs 131 registers, the
+// mixed body 135: three wavefronts).  The edge blocks come first so that their longer per-record chain (the Jacobi
+// eigen-solver) runs under the plane blocks instead of forming the launch's tail.
+__global__ void __launch_bounds__(kAssocBlock, 4)
+fit_scan2map_split_kernel(BatchView bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
+                          const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
+                          double* __restrict__ rec, double* __restrict__ full, int edge_blocks) {
+  if ((int)blockIdx.x < edge_blocks) fit_one<false, 1>(bv, map_c, map_s, nn, line_ratio, plane_tol, dv, rec, full, (int)blockIdx.x);
+  else fit_one<false, 2>(bv, map_c, map_s, nn, line_ratio, plane_tol, dv, rec, full, (int)blockIdx.x - edge_blocks);
 }
 
 // {C, N} x n_records (host/debug format) -> compact internal records
