@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-ASSOC_KERNEL_PREFIX = "knn5_scan2map_kernel"   # the dominant kernel (rocprofv3 name prefix; template arguments follow)
+ASSOC_KERNEL_PREFIX = "knn5_scan2map_split_kernel"   # the dominant kernel (rocprofv3 name prefix): the whole-batch form of the 5-NN search
 
 
 def build_inputs(B, map_points, seed_offset, extractor=None, scan_ids=None, with_map=True):
@@ -176,7 +176,7 @@ def valu_roof(kernel_prefix, launch_ms):
     except OSError:
         return None
     hit = [k for k in pt["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>") and "sq_insts_valu" in pt["kernels"][k]]
-    mk = [k for k in mix["kernels"] if k.replace(" ", "") in (kernel_prefix + "<false,false>", kernel_prefix + "_split_kernel", kernel_prefix + "<128>")] or \
+    mk = [k for k in mix["kernels"] if k.replace(" ", "") in (kernel_prefix, kernel_prefix + "<false,false>", kernel_prefix + "_split_kernel", kernel_prefix + "<128>")] or \
          [k for k in mix["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>")]
     if not hit or not mk or launch_ms <= 0:
         return None
@@ -433,7 +433,7 @@ def main():
                        "scans_per_gpu": B if not strong else cap, "total_scans": total_scans, "map_points": n_mc + n_ms, "map_corner": n_mc, "map_surf": n_ms,
                        "features_per_scan": F_total / B, "feature_source": feature_source,
                        "index_rebuilt_per_step": True, "parallelism": "scan-sharded x%d, map replicated" % world_size},
-            "roofline": {"bound": roof_bound, "kernel": "knn5_scan2map_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": roof_bound, "kernel": ASSOC_KERNEL_PREFIX, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes_assoc, "avg_launch_ms": assoc_ms, "valu": valu,
                          "bound_note": "achieved / peak / frac are the HBM figures on ALGORITHMIC bytes (SURVEY.md 8d); `bound` names the roof the "

@@ -320,6 +320,13 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
                            (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
                            (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
                            h->prm.map_knn_max_sq_dist, dv, nn, cnt);
+    } else if (!deskew && !bv.dyn && rec_end < 0 && n_rec >= 65536) {       // a whole large batch: one body per feature kind (-2 %)
+      const int n_s = bv.n_surf_total, n_c = n_rec - n_s;
+      const int edge_blocks = div_up(n_c, kAssocBlock), plane_blocks = div_up(n_s, kAssocBlock);
+      hipLaunchKernelGGL(knn5_scan2map_split_kernel, dim3(edge_blocks + plane_blocks), block, 0, st, bv, d_poses, d_status,
+                         (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                         (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                         (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(), h->prm.map_knn_max_sq_dist, nn, edge_blocks);
     } else if (!deskew && (h->knn_form == 2 || (h->knn_form == 0 && n_rec <= kKnnRowsMaxRecords)))
       hipLaunchKernelGGL(knn5_scan2map_rows_kernel, dim3(div_up(n_rec, kKnnRowsBlock / kKnnRowLanes)), dim3(kKnnRowsBlock), 0, st, bv, d_poses, d_status,
                          (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),

@@ -545,6 +545,43 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   }
 }
 
+// K4a for a whole large batch of the plain branch: blocks [0, edge_blocks) serve the corner features (corner map index), the rest
+// the surf features, so that a wavefront never holds both kinds and each body knows its map at compile time.
+template <bool EDGE>
+__device__ __forceinline__ void knn5_one_kind(const BatchView& bv, const double* __restrict__ poses, const int* __restrict__ status,
+                                              const GridDesc* __restrict__ gp, const float4* __restrict__ map, const int* __restrict__ cs,
+                                              const int* __restrict__ po, float max_sq_dist, int* __restrict__ nn, int block) {
+  const int* off = EDGE ? bv.corner_off : bv.surf_off;
+  const int f_i = off[0] + block * (int)blockDim.x + (int)threadIdx.x;
+  if (f_i >= off[bv.n_scans]) return;
+  const int b = find_scan_wave(off, bv.n_scans, f_i);
+  const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
+  const int g = bv.rec_off[b] + (EDGE ? 0 : nc) + (f_i - off[b]);
+  int* out = nn + 5 * (size_t)g;
+  if (status[b] != 0) { out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1; return; }
+  const float4 f = EDGE ? bv.corner[f_i] : bv.surf[f_i];
+  const pose7 T = load_pose(poses + 7 * b);
+  const float3 q = transform_point_f32(T, f.x, f.y, f.z);                          // :123 / :193
+  Top5 t;
+  int n_cand = 0;
+  const GridDesc gd = *gp;
+  knn5_grid(gd, map, cs, q, max_sq_dist, t, n_cand);
+  if ((unsigned int)t.k4 != 0xffffffffu && (double)top5_d4(t) < (double)max_sq_dist) {      // :128 / :198
+    out[0] = po[(unsigned int)t.k0]; out[1] = po[(unsigned int)t.k1]; out[2] = po[(unsigned int)t.k2];
+    out[3] = po[(unsigned int)t.k3]; out[4] = po[(unsigned int)t.k4];       // nearest first
+  } else {
+    out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1;
+  }
+}
+__global__ void __launch_bounds__(kAssocBlock)
+knn5_scan2map_split_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
+                           const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
+                           const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
+                           const int* __restrict__ pos_c, const int* __restrict__ pos_s, float max_sq_dist, int* __restrict__ nn, int edge_blocks) {
+  if ((int)blockIdx.x < edge_blocks) knn5_one_kind<true>(bv, poses, status, gcp, map_c, cs_c, pos_c, max_sq_dist, nn, (int)blockIdx.x);
+  else knn5_one_kind<false>(bv, poses, status, gsp, map_s, cs_s, pos_s, max_sq_dist, nn, (int)blockIdx.x - edge_blocks);
+}
+
 // K4a, latency form: the same exact 5-NN for a launch too small to fill the machine (one scan per call: ~5 000 queries are
 // 80 wavefronts on 1 024 SIMDs, and a query is a chain of up to nine dependent row-bound -> candidate load round trips,
 // ~35 us).  Sixteen lanes serve one query: lane r < 9 owns row r of the 3 x 3 (y, z) neighbourhood, reads its two row
