@@ -44,7 +44,10 @@ def kernels(asm):
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_valu_mix.json")
+    import argparse
+    ap = argparse.ArgumentParser(description="static VALU instruction mix of every msfl kernel (ISA of the gfx950 build)")
+    ap.add_argument("-o", "--out", default=os.path.join(ROOT, "profiles", "r03_valu_mix.json"), help="JSON file to write")
+    out = ap.parse_args().out
     with tempfile.TemporaryDirectory() as td:
         s = os.path.join(td, "dev.s")
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-w", "-S", "--cuda-device-only",
