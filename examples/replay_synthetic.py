@@ -82,7 +82,39 @@ class GpuBackend:
         return self.capi.Grid(self.mapper, 3.0, 0.2), self.capi.Grid(self.mapper, 3.0, 0.4)   # laser_mapping.cc:44-45,60-68
 
 
-def run(backend, world, poses_true, verbose=False, maps_out=None, scans=None):
+def synthetic_imu(poses_true, switch_at=50, seed=synth.SEED + 900, samples=45):
+    """Per-scan IMU inputs for the replay (msfl_slam_imu): a synthetic pre-integration (45 samples over 0.11 s: a small steady
+    rotation + drift, so that the de-skew passes change every point by millimetres), the estimator "initialised" from scan
+    `switch_at` on (estimator.h:57: 50 scans), the pre-solved pose = the true pose nudged by a few millimetres (an IMU
+    prediction that does not depend on earlier results, so the pipelined form can be fed without waiting)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k, pose in enumerate(poses_true):
+        sum_dt = np.linspace(0.0, 0.11, samples)
+        w = rng.normal(0, 0.02, 3)                                   # rad/s
+        acc = rng.normal(0, 0.05, 3)
+        v_body = rng.normal(0, 0.03, 3)
+        ang = sum_dt[:, None] * w[None, :]
+        half = 0.5 * np.linalg.norm(ang, axis=1)
+        axis = w / max(np.linalg.norm(w), 1e-12)
+        dq = np.c_[np.sin(half)[:, None] * axis[None, :], np.cos(half)]
+        dp = v_body[None, :] * sum_dt[:, None] + 0.5 * acc[None, :] * sum_dt[:, None] ** 2
+        init = k >= switch_at
+        pres = pose.copy()
+        pres[:3] += rng.normal(0, 0.004, 3)
+        dth = rng.normal(0, 0.001, 3)
+        q = synth.quat_mul(pose[3:], np.r_[0.5 * dth, 1.0])
+        pres[3:] = q / np.linalg.norm(q)
+        out.append(dict(sum_dt=sum_dt, delta_q=dq, delta_p=dp, is_initialized=init, velocity=rng.normal(0, 0.05, 3),
+                        gravity=np.array([0.0, 0.0, 0.3]) + rng.normal(0, 0.01, 3), presolved_pose=pres))
+    return out
+
+
+def run(backend, world, poses_true, verbose=False, maps_out=None, scans=None, quirks=False, imu=None):
+    """quirks: FilterLessFlatLessCornerFeature as the reference executes it (laser_mapping.cc:340-364: the surf cloud cut to its first
+    n_less_sharp points).  imu: per-scan dicts (synthetic_imu) -> UndistortScan before the match while not initialised
+    (:170-176), the is_initialized matcher branch + DoUndistort before the insert afterwards (:197-211); needs a backend with
+    undistort / deskew / scan2map_deskew (the oracle backend of the tests)."""
     # a backend may bring its own Rigid3d algebra (the oracle-driven loop of the tests uses the oracle's quaternion forms)
     compose_ = getattr(backend, "compose", compose)
     inverse_ = getattr(backend, "inverse", inverse)
@@ -101,19 +133,37 @@ def run(backend, world, poses_true, verbose=False, maps_out=None, scans=None):
             curr2last = backend.scan2scan(last, f, curr2last)                 # laser_odometry.cc:75 (guess = last delta)
             odo2first = compose_(odo2first, curr2last)                        # :79
         t2 = time.perf_counter()
-        corner = backend.voxel(f["full"][f["less_sharp"]], 0.2)               # laser_mapping.cc:264-270
-        surf = backend.voxel(f["full"][f["less_flat"]], 0.4)
+        # ---- mapping thread (LaserMapping::Run): its own copies of the two clouds that reach the pose and the map
+        ls, lf = f["full"][f["less_sharp"]], f["full"][f["less_flat"]]
+        im = imu[k] if imu is not None else None
+        if im is not None and im["sum_dt"] is None:
+            im = None
+        pre = (im["sum_dt"], im["delta_q"], im["delta_p"]) if im is not None else None
+        if im is not None and not im["is_initialized"]:                        # UndistortScan, laser_mapping.cc:170-176
+            ls, lf = backend.undistort(pre, ls), backend.undistort(pre, lf)
+        if quirks:                                                            # FilterLessFlatLessCornerFeature, :186,340-364
+            assert len(ls) <= len(lf), "the reference reads out of bounds here"
+            lf = lf[:len(ls)]
+        corner = backend.voxel(ls, 0.2)                                       # laser_mapping.cc:264-270
+        surf = backend.voxel(lf, 0.4)
         t3 = time.perf_counter()
         pose_map = compose_(odom2map, odo2first)                              # TransformAssociateToMap, laser_mapping.h:55-57
-        map_c = grid_c.get_surrounded(f["full"][f["less_sharp"]], pose_map)   # GetSurroundedCloud on the UN-down-sampled
-        map_s = grid_s.get_surrounded(f["full"][f["less_flat"]], pose_map)    # feature clouds, laser_mapping.cc:273-278
+        map_c = grid_c.get_surrounded(ls, pose_map)                           # GetSurroundedCloud on the UN-down-sampled
+        map_s = grid_s.get_surrounded(lf, pose_map)                           # feature clouds, laser_mapping.cc:273-278
         t3b = time.perf_counter()
         if len(map_c) > 10 and len(map_s) > 50:                               # gate, laser_mapping.cc:284-285
-            pose_map = backend.scan2map(map_c, map_s, corner, surf, pose_map)
+            if im is not None and im["is_initialized"]:                       # mapping_scan_matcher.cc:28-59: start from the pre-solve
+                pose_map = backend.scan2map_deskew(map_c, map_s, corner, surf, pre, im["velocity"], im["gravity"],
+                                                   np.array(im["presolved_pose"], np.float64))
+            else:
+                pose_map = backend.scan2map(map_c, map_s, corner, surf, pose_map)
         t4 = time.perf_counter()
         odom2map = compose_(pose_map, inverse_(odo2first))                    # TransformUpdate, laser_mapping.h:59-61
-        grid_c.insert_scan(transform_(pose_map, f["full"][f["less_sharp"]]))   # InsertScan2Map, laser_mapping.cc:330-338
-        grid_s.insert_scan(transform_(pose_map, f["full"][f["less_flat"]]))
+        if im is not None and im["is_initialized"]:                           # DoUndistort, laser_mapping.cc:197-211 (pose_odom_scan2world_!)
+            ls = backend.deskew(pre, ls, odo2first[3:], im["velocity"], im["gravity"])
+            lf = backend.deskew(pre, lf, odo2first[3:], im["velocity"], im["gravity"])
+        grid_c.insert_scan(transform_(pose_map, ls))                          # InsertScan2Map, laser_mapping.cc:330-338
+        grid_s.insert_scan(transform_(pose_map, lf))
         t5 = time.perf_counter()
         last = f
         est.append(pose_map)
@@ -129,7 +179,7 @@ def run(backend, world, poses_true, verbose=False, maps_out=None, scans=None):
     return np.array(est), {k: 1e3 * v / m for k, v in t_stage.items()}
 
 
-def run_slam(world, poses_true, pipelined=False, device=0, scans=None, verbose=False, maps_out=None):
+def run_slam(world, poses_true, pipelined=False, device=0, scans=None, verbose=False, maps_out=None, quirks=False, imu=None):
     """The same loop through the device-resident SLAM step (msfl_slam_add_scan): raw scan in, pose out, one
     synchronisation per scan (pipelined=False) or none until the record is fetched one scan later (pipelined=True: the
     odometry chain of scan k + 1 runs under the mapping chain of scan k, like the reference's two threads).
@@ -139,18 +189,20 @@ def run_slam(world, poses_true, pipelined=False, device=0, scans=None, verbose=F
     if scans is None:
         scans = [synth.make_scan(world, poses_true[k], synth.SEED + 5000 + k) for k in range(n)]
     cap = max(len(p) for p, _ in scans)
-    slam = capi.Slam(device, max_scan_points=cap, max_rings=int(max(r.max() for _, r in scans)) + 1, pose_odom2map=poses_true[0])
+    slam = capi.Slam(device, max_scan_points=cap, max_rings=int(max(r.max() for _, r in scans)) + 1, pose_odom2map=poses_true[0],
+                     reference_quirks=1 if quirks else 0)
     recs = [None] * n
     t_start = None
     for k in range(n):
         if k == 2:
             t_start = time.perf_counter()
+        im = imu[k] if imu is not None else None
         if pipelined:
-            slam.add_scan(*scans[k], wait=False)
+            slam.add_scan(*scans[k], wait=False, imu=im)
             if k >= 1:
                 recs[k - 1] = slam.result(k - 1)
         else:
-            recs[k] = slam.add_scan(*scans[k])
+            recs[k] = slam.add_scan(*scans[k], imu=im)
         if verbose and k % 50 == 0 and recs[max(k - 1, 0)] is not None:
             r = recs[max(k - 1, 0)]
             print(k, list(r.grid_corner)[:3], list(r.grid_surf)[:3], r.status_mapping, file=sys.stderr)
@@ -175,6 +227,8 @@ def main():
     ap.add_argument("--mode", choices=["slam", "slam-pipelined", "staged"], default="slam",
                     help="slam: msfl_slam_add_scan, one synchronisation per scan; slam-pipelined: results fetched one scan late; "
                          "staged: the round-2 loop of single-stage host-pointer calls")
+    ap.add_argument("--reference-quirks", action="store_true", help="msfl_slam_config.reference_quirks = 1 (surf list truncation of the reference)")
+    ap.add_argument("--imu", action="store_true", help="feed a synthetic pre-integration with every scan (UndistortScan, then the is_initialized branch from scan 50)")
     args = ap.parse_args()
     world = synth.World(ground_half=45.0)
     truth = trajectory(args.scans)
@@ -187,9 +241,11 @@ def main():
     scans = [synth.make_scan(world, truth[k], synth.SEED + 5000 + k) for k in range(args.scans)]
     import gc
     gc.collect(); gc.disable()
-    est, recs, ms = run_slam(world, truth, pipelined=args.mode == "slam-pipelined", scans=scans)
+    est, recs, ms = run_slam(world, truth, pipelined=args.mode == "slam-pipelined", scans=scans, quirks=args.reference_quirks,
+                             imu=synthetic_imu(truth) if args.imu else None)
     last = recs[-1]
-    print(json.dumps({"mode": args.mode, "scans": args.scans, "ate_rmse_m": ate(est, truth),
+    print(json.dumps({"mode": args.mode, "scans": args.scans, "reference_quirks": bool(args.reference_quirks), "imu": bool(args.imu),
+                      "ate_rmse_m": ate(est, truth),
                       "final_error_m_rad": synth.pose_error(est[-1], truth[-1]), "ms_per_scan_end_to_end": ms,
                       "scans_per_s": 1e3 / ms if ms else None,
                       "map_points": [last.grid_corner[0], last.grid_surf[0]], "map_cells": [last.grid_corner[1], last.grid_surf[1]],

@@ -475,7 +475,11 @@ msfl_status msfl_grid_dump(msfl_grid* g, msfl_point* out, int capacity, int* n_o
 /*     LaserMapping::Run             TransformAssociateToMap, MatchScan2Map (voxel filters,      */
 /*                                   GetSurroundedCloud x2, gate, scan-to-map), TransformUpdate, */
 /*                                   InsertScan2Map x2             laser_mapping.cc:138-258,260-338 */
-/*   LiDAR-only branch (estimator not initialised: no de-skew, no IMU pre-solve).                */
+/*   msfl_slam_add_scan is the LiDAR-only form (no IMU data: nothing to de-skew with);           */
+/*   msfl_slam_add_scan_imu takes the per-scan IMU inputs and runs what LaserMapping::Run runs    */
+/*   with them: UndistortScan before the match while the estimator is not initialised             */
+/*   (laser_mapping.cc:170-176), the is_initialized matcher branch from the pre-solved pose        */
+/*   (mapping_scan_matcher.cc:28-59,100-121) + DoUndistort before the insert (:197-211) once it is.*/
 /* Raw points in, poses out: every intermediate (features, down-sampled clouds, the surrounded    */
 /* map clouds, their kNN index, the two HybridGrid stores, the pose chain) stays in HBM, all        */
 /* sizes are read by the kernels from device memory, and nothing synchronises with the host        */
@@ -496,6 +500,15 @@ typedef struct msfl_slam_config {
   int    max_scan_points;     /* largest scan add_scan will see (capacity of the device buffers), e.g. 28 800 for a VLP-16 */
   int    max_rings;           /* rings of the sensor (16 / 64 / 128): bounds the per-scan sharp / flat counts the launches are sized for */
   double pose_odom2map[7];    /* initial pose_odom2map_ (identity in the reference, laser_mapping.h:88) */
+  /* 0 (default): the mapping thread works on the scan's whole less-flat cloud, which is what FilterLessFlatLessCornerFeature
+        (laser_mapping.cc:186,340-364) evidently means to do.
+     1: reproduce what that function DOES: it copies cloud_surf_less_flat through the index list of the CORNER filter
+        (`indices = downsize_filter_corner_.getIndices()` at :359 after the surf filter ran), i.e. the surf cloud is cut to its
+        first n_less_sharp points, and that truncated cloud is what is voxel-filtered, used for GetSurroundedCloud, matched AND
+        inserted into the map.  Use it to compare trajectories / maps with the real binary.  A scan with MORE less-sharp than
+        less-flat points makes the reference read out of bounds (pcl::copyPointCloud); here: status_mapping = MSFL_BAD_ARG,
+        status_imu untouched, the scan is neither matched nor inserted. */
+  int    reference_quirks;
 } msfl_slam_config;
 
 typedef struct msfl_slam_result {
@@ -513,6 +526,11 @@ typedef struct msfl_slam_result {
   int n_corner_ds, n_surf_ds;           /* after the 0.2 / 0.4 m voxel filters (:264-270) */
   int n_map_corner, n_map_surf;         /* GetSurroundedCloud sizes (:273-278) */
   int grid_corner[8], grid_surf[8];     /* map store after the inserts: {points, cells, pool_top, dropped, overflow, cells touched, ...} */
+  int status_imu;             /* 0, or MSFL_BAD_ARG: a less-sharp / less-flat point's relative time lies outside the scan's
+                                 pre-integration span (GetDeltaQP CHECK-aborts there, scan_undistortion.cc:26-30; CHECK_GE(time, 0) :12):
+                                 the scan is then neither matched nor inserted (status_mapping = MSFL_BAD_ARG as well) */
+  int status_insert;          /* 0, or MSFL_CAPACITY: one of the two InsertScan calls was dropped (grid_*[3] / [4] != 0: a point outside
+                                 the +-8192-cell range / not finite, or an internal capacity); the map store is then unchanged */
 } msfl_slam_result;
 
 void msfl_slam_default_config(msfl_slam_config* c);
@@ -530,6 +548,39 @@ void msfl_slam_destroy(msfl_slam* s);
    Returns a status for argument / HIP errors only; per-scan outcomes are in the record. */
 msfl_status msfl_slam_add_scan(msfl_slam* s, const msfl_point* pts, const uint16_t* ring, int n, msfl_mem mem,
                                msfl_slam_result* result);
+
+/* Per-scan IMU inputs of LaserMapping::Run.  Everything here is produced by code OUTSIDE the hot path (IMU pre-integration,
+   the estimator, the 15-residual IMU-only pre-solve: SURVEY.md 8f N3) and handed over like the reference's members:
+     pre            BuildPreintegration(imu_buf_, odom_result.time) (laser_mapping.cc:191-194, :399); NULL = no IMU data for
+                    this scan (the step then behaves like msfl_slam_add_scan, whatever is_initialized says)
+     is_initialized estimator_.IsInitialized() (:173,:197; the reference switches after kInitByFirstScanNums = 50 scans, estimator.h:57)
+       0: UndistortScan (:170-176 -> scan_undistortion.cc:5-19,45-62): p <- dq(p.time).cast<float>() * p on the clouds the mapping
+          thread works with, BEFORE FilterLessFlatLessCornerFeature, the voxel filters, GetSurroundedCloud, the match and the insert;
+          velocity / gravity / presolved_pose are not read
+       1: the match starts from presolved_pose (pose_j of the IMU-only Ceres problem, mapping_scan_matcher.cc:35-59; the caller solves
+          it, cf. MappingScanMatcher::SetImuPresolve in include/msfl/scan_matcher.hpp) and uses the Deskew factors with
+          (dq, dp) = GetDeltaQP(pre, t) per down-sampled feature, Vi = velocity held constant (:94) and `gravity` (:100-121,154-166,
+          224-236); afterwards DoUndistort (:197-211) rewrites the clouds that InsertScan2Map then inserts:
+            p <- (dq(t) * p + pose_odom.rotation()^-1 * (velocity * t - 0.5 * gravity * t * t) + dp(t)).cast<float>()
+          GetSurroundedCloud still uses TransformAssociateToMap's pose (:185,:273-278), like the reference.
+   The odometry thread (MatchScan2Scan) never sees any of this: it works on the raw feature clouds (laser_odometry.cc:69-95).
+   Which clouds: cloud_corner_less_sharp and cloud_surf_less_flat, the two that reach the pose and the map.  The reference also
+   rewrites cloud_full_res (published / accumulated for the PLY dump only) and, in the not-initialised branch, the sharp / flat clouds,
+   which nothing reads afterwards (FilterLessFlatLessCornerFeature hands on EMPTY sharp / flat clouds, :344-345); for those use
+   msfl_undistort_cloud / msfl_deskew_cloud on the extraction output.
+   `pre` holds at most 2 048 samples (MSFL_CAPACITY beyond); the arrays are copied before the call returns. */
+typedef struct msfl_slam_imu {
+  const msfl_preintegration* pre;
+  int    is_initialized;
+  double velocity[3];         /* velocity_ = bias_j.head<3>() of the pre-solve (mapping_scan_matcher.cc:58) */
+  double gravity[3];          /* estimator_.GetGravityVector() */
+  double presolved_pose[7];   /* pose_j (:57) */
+} msfl_slam_imu;
+
+/* msfl_slam_add_scan with the scan's IMU inputs (imu == NULL: identical to msfl_slam_add_scan).  With is_initialized = 1 the
+   pre-solve needs the previous scan's mapping result, so a caller normally fetches that result before feeding the next scan. */
+msfl_status msfl_slam_add_scan_imu(msfl_slam* s, const msfl_point* pts, const uint16_t* ring, int n, msfl_mem mem,
+                                   const msfl_slam_imu* imu, msfl_slam_result* result);
 
 /* Wait for the scan with the given index (one of the last four fed) and deliver its record. */
 msfl_status msfl_slam_get_result(msfl_slam* s, int scan_index, msfl_slam_result* result);

@@ -26,7 +26,7 @@ EXPORTED = [
     "msfl_transform_cloud",
     "msfl_delta_qp", "msfl_deskew_cloud", "msfl_undistort_cloud",
     "msfl_grid_create", "msfl_grid_destroy", "msfl_grid_insert_scan", "msfl_grid_get_surrounded", "msfl_grid_size", "msfl_grid_dump",
-    "msfl_slam_default_config", "msfl_slam_create", "msfl_slam_destroy", "msfl_slam_add_scan", "msfl_slam_get_result", "msfl_slam_grids",
+    "msfl_slam_default_config", "msfl_slam_create", "msfl_slam_destroy", "msfl_slam_add_scan", "msfl_slam_add_scan_imu", "msfl_slam_get_result", "msfl_slam_grids",
     "msfl_slam_last_error",
 ]
 
@@ -107,7 +107,13 @@ class FeaturesBatch(C.Structure):
 class SlamConfig(C.Structure):
     _fields_ = [("map_resolution", C.c_float), ("leaf_corner", C.c_float), ("leaf_surf", C.c_float),
                 ("min_map_corner", C.c_int), ("min_map_surf", C.c_int), ("max_scan_points", C.c_int), ("max_rings", C.c_int),
-                ("pose_odom2map", C.c_double * 7)]
+                ("pose_odom2map", C.c_double * 7), ("reference_quirks", C.c_int)]
+
+
+class SlamImu(C.Structure):
+    """msfl_slam_imu: the per-scan IMU inputs of LaserMapping::Run (laser_mapping.cc:170-176,197-211)."""
+    _fields_ = [("pre", C.POINTER(Preintegration)), ("is_initialized", C.c_int), ("velocity", C.c_double * 3),
+                ("gravity", C.c_double * 3), ("presolved_pose", C.c_double * 7)]
 
 
 class SlamResult(C.Structure):
@@ -116,7 +122,7 @@ class SlamResult(C.Structure):
                 ("scan_index", C.c_int), ("status_extract", C.c_int), ("status_mapping", C.c_int),
                 ("n_full", C.c_int), ("n_sharp", C.c_int), ("n_less_sharp", C.c_int), ("n_flat", C.c_int), ("n_less_flat", C.c_int),
                 ("n_corner_ds", C.c_int), ("n_surf_ds", C.c_int), ("n_map_corner", C.c_int), ("n_map_surf", C.c_int),
-                ("grid_corner", C.c_int * 8), ("grid_surf", C.c_int * 8)]
+                ("grid_corner", C.c_int * 8), ("grid_surf", C.c_int * 8), ("status_imu", C.c_int), ("status_insert", C.c_int)]
 
 
 class MsflError(RuntimeError):
@@ -569,12 +575,36 @@ class Slam:
         except Exception:
             pass
 
-    def add_scan(self, pts, ring, wait=True):
-        """Feed one scan (host arrays).  wait=True: returns this scan's SlamResult; False: enqueue only."""
+    @staticmethod
+    def make_imu(sum_dt, delta_q, delta_p, is_initialized=False, velocity=(0, 0, 0), gravity=(0, 0, 0), presolved_pose=None):
+        """Build an msfl_slam_imu (returns (struct, keep-alive tuple)); sum_dt None = no IMU data for the scan."""
+        imu = SlamImu()
+        keep = None
+        if sum_dt is not None:
+            pre, arrays = Handle._preintegration(sum_dt, delta_q, delta_p)
+            keep = (pre, arrays)
+            imu.pre = C.pointer(pre)
+        imu.is_initialized = 1 if is_initialized else 0
+        for k in range(3):
+            imu.velocity[k], imu.gravity[k] = float(velocity[k]), float(gravity[k])
+        pp = presolved_pose if presolved_pose is not None else (0, 0, 0, 0, 0, 0, 1)
+        for k in range(7):
+            imu.presolved_pose[k] = float(pp[k])
+        return imu, keep
+
+    def add_scan(self, pts, ring, wait=True, imu=None):
+        """Feed one scan (host arrays).  wait=True: returns this scan's SlamResult; False: enqueue only.
+        imu: a dict of make_imu's arguments (msfl_slam_add_scan_imu), or None (LiDAR-only)."""
         pts = _pts(pts)
         ring = np.ascontiguousarray(ring, dtype=np.uint16)
         r = SlamResult() if wait else None
-        st = self.lib.msfl_slam_add_scan(self.s, _vp(pts), _vp(ring), C.c_int(len(pts)), C.c_int(MEM_HOST), C.byref(r) if wait else None)
+        if imu is None:
+            st = self.lib.msfl_slam_add_scan(self.s, _vp(pts), _vp(ring), C.c_int(len(pts)), C.c_int(MEM_HOST), C.byref(r) if wait else None)
+        else:
+            im, keep = self.make_imu(**imu)
+            st = self.lib.msfl_slam_add_scan_imu(self.s, _vp(pts), _vp(ring), C.c_int(len(pts)), C.c_int(MEM_HOST), C.byref(im),
+                                                 C.byref(r) if wait else None)
+            del keep
         if st != OK:
             raise MsflError(st, "msfl_slam_add_scan", self._err())
         self.n_scans += 1

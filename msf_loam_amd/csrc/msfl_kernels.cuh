@@ -474,6 +474,7 @@ struct DeskewView {
   const double* surf_dq;   const double* surf_dp;
   const double* V;          // n_scans x 3 (device): Vi of every scan
   double G[3];
+  const double* G_dev;      // gravity in device memory (the SLAM step's per-scan IMU block); null: G above
   double* pprime;           // out: n_records x 3, p' = dq*p + dp
 };
 
@@ -511,8 +512,9 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
     const d3 dp = mk3(dpp[0], dpp[1], dpp[2]);
     const double dt = (double)f.w;
     const double* Vb = dv.V + 3 * (size_t)b;
-    const d3 shift = mk3(Vb[0] * dt - 0.5 * dv.G[0] * dt * dt, Vb[1] * dt - 0.5 * dv.G[1] * dt * dt,
-                         Vb[2] * dt - 0.5 * dv.G[2] * dt * dt);
+    const double Gv[3] = {dv.G_dev ? dv.G_dev[0] : dv.G[0], dv.G_dev ? dv.G_dev[1] : dv.G[1], dv.G_dev ? dv.G_dev[2] : dv.G[2]};
+    const d3 shift = mk3(Vb[0] * dt - 0.5 * Gv[0] * dt * dt, Vb[1] * dt - 0.5 * Gv[1] * dt * dt,
+                         Vb[2] * dt - 0.5 * Gv[2] * dt * dt);
     quat qc; qc.x = -T.q.x; qc.y = -T.q.y; qc.z = -T.q.z; qc.w = T.q.w;
     pose7 full;
     full.t = quat_rotate(T.q, quat_rotate(qc, shift) + dp) + T.t;       // Rigid3d operator*
@@ -719,8 +721,9 @@ __device__ __forceinline__ void fit_one(const BatchView& bv, const float4* __res
       const int fi = is_edge ? bv.corner_off[b] + local : bv.surf_off[b] + (local - nc);
       const double dt = (double)(is_edge ? bv.corner[fi].w : bv.surf[fi].w);
       const double* Vb = dv.V + 3 * (size_t)b;
-      fo.C = fo.C - mk3(Vb[0] * dt - 0.5 * dv.G[0] * dt * dt, Vb[1] * dt - 0.5 * dv.G[1] * dt * dt,
-                        Vb[2] * dt - 0.5 * dv.G[2] * dt * dt);
+      const double Gv[3] = {dv.G_dev ? dv.G_dev[0] : dv.G[0], dv.G_dev ? dv.G_dev[1] : dv.G[1], dv.G_dev ? dv.G_dev[2] : dv.G[2]};
+      fo.C = fo.C - mk3(Vb[0] * dt - 0.5 * Gv[0] * dt * dt, Vb[1] * dt - 0.5 * Gv[1] * dt * dt,
+                        Vb[2] * dt - 0.5 * Gv[2] * dt * dt);
     }
   }
   if (is_edge) {

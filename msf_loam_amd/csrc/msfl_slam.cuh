@@ -11,15 +11,51 @@
 
 #include "msfl_math.cuh"
 #include "msfl_grid.cuh"
+#include "msfl_deskew.cuh"
 
 namespace msfl {
 
 // counts block of one scan, written by the extraction kernels: [n_full, n_sharp, n_less_sharp, n_flat, n_less_flat, status, -, -]
-enum { SC_FULL = 0, SC_SHARP, SC_LESS_SHARP, SC_FLAT, SC_LESS_FLAT, SC_STATUS, SC_OVERFLOW, SC_USE_LS, SC_USE_LF, SC_WORDS = 12 };
+enum { SC_FULL = 0, SC_SHARP, SC_LESS_SHARP, SC_FLAT, SC_LESS_FLAT, SC_STATUS, SC_OVERFLOW, SC_USE_LS, SC_USE_LF, SC_IMU_BAD, SC_QUIRK_OOB,
+       SC_WORDS = 12 };
+// SC_IMU_BAD: a less-sharp / less-flat point's time lies outside the scan's pre-integration span (raised by the gather kernel's lanes,
+// cleared by slam_result_kernel once the record is assembled); SC_QUIRK_OOB: reference_quirks and more less-sharp than less-flat points
 // SC_USE_LS / SC_USE_LF: the less-sharp / less-flat counts the mapping thread works with: the extraction's, or 0 for a scan that is
 // not processed (failed extraction, a list beyond the launch bounds), so that such a scan is neither matched nor inserted
 
 struct SlamCaps { int sharp, less_sharp, flat, less_flat; };     // host-side bounds the launches are sized for
+
+// The scan's IMU inputs on the device (msfl_slam_imu), one block per buffer set, uploaded in one copy: header, then the
+// pre-integration samples packed as [sum_dt n | delta_q 4n | delta_p 3n].
+constexpr int kSlamImuMaxSamples = 2048;
+struct SlamImuDev {
+  int mode;                 // 0: no IMU data; 1: UndistortScan (estimator not initialised); 2: is_initialized
+  int n;                    // samples
+  double velocity[3], gravity[3], presolved[7];
+  double data[8 * kSlamImuMaxSamples];
+};
+__device__ __forceinline__ PreintView slam_preint(const SlamImuDev* __restrict__ imu) {
+  PreintView pv;
+  pv.n = imu->n; pv.sum_dt = imu->data; pv.dq = imu->data + imu->n; pv.dp = imu->data + 5 * (size_t)imu->n;
+  return pv;
+}
+// The mapping thread's copy of one less-sharp / less-flat point (the odometry thread keeps the raw one):
+//   mode 1: UndistortScanInternal (scan_undistortion.cc:5-19): p <- dq(p.time).cast<float>() * p, CHECK_GE(time, 0) (:12) and
+//           GetDeltaQP's range CHECK (:26-30) -> *bad
+//   mode 2: unchanged here (DoUndistort runs after the match, laser_mapping.cc:197-211), but the same range CHECK is due then and
+//           inside the matcher (mapping_scan_matcher.cc:115,185): validated now, while nothing has been published
+__device__ __forceinline__ float4 slam_map_point(float4 e, int mode, const PreintView& pv, int* __restrict__ bad) {
+  if (mode == 0) return e;
+  const DeltaQP o = delta_qp(pv, (double)e.w);
+  if (!o.ok || (mode == 1 && !(e.w >= 0.f))) { *bad = 1; return e; }
+  if (mode == 2) return e;
+  const float qx = (float)o.q.x, qy = (float)o.q.y, qz = (float)o.q.z, qw = (float)o.q.w;       // as undistort_cloud_kernel
+  float ux = qy * e.z - qz * e.y, uy = qz * e.x - qx * e.z, uz = qx * e.y - qy * e.x;
+  ux += ux; uy += uy; uz += uz;
+  const float cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
+  e.x = e.x + qw * ux + cx; e.y = e.y + qw * uy + cy; e.z = e.z + qw * uz + cz;
+  return e;
+}
 
 // The four feature clouds of TimestampedPointCloud (timestamped_pointcloud.h:11-42) as contiguous arrays: the reference
 // push_back()s copies (msf_loam_node.cc:279-344); here one gather out of cloud_full_res per list.  Also writes the five
@@ -30,7 +66,8 @@ slam_gather_kernel(const float4* __restrict__ full, const uint16_t* __restrict__
                    const int* __restrict__ ls_idx, const int* __restrict__ flat_idx, const int* __restrict__ lf_idx, int* __restrict__ cnt,
                    SlamCaps caps, float4* __restrict__ sharp_pts, float4* __restrict__ ls_pts, uint16_t* __restrict__ ls_ring,
                    float4* __restrict__ flat_pts, float4* __restrict__ lf_pts, uint16_t* __restrict__ lf_ring,
-                   const int* __restrict__ last_cnt, SlamCaps last_caps, int* __restrict__ odo_off, int* __restrict__ odo_status) {
+                   const int* __restrict__ last_cnt, SlamCaps last_caps, int* __restrict__ odo_off, int* __restrict__ odo_status,
+                   const SlamImuDev* __restrict__ imu, float4* __restrict__ map_ls, float4* __restrict__ map_lf, int quirks) {
   const int list = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool ok = cnt[SC_STATUS] == 0;
   const int n_sharp = ok ? min(cnt[SC_SHARP], caps.sharp) : 0, n_ls = ok ? min(cnt[SC_LESS_SHARP], caps.less_sharp) : 0;
@@ -46,14 +83,29 @@ slam_gather_kernel(const float4* __restrict__ full, const uint16_t* __restrict__
     const int over = ok && (cnt[SC_SHARP] > caps.sharp || cnt[SC_LESS_SHARP] > caps.less_sharp || cnt[SC_FLAT] > caps.flat ||
                             cnt[SC_LESS_FLAT] > caps.less_flat) ? 1 : 0;
     cnt[SC_OVERFLOW] = over;
-    cnt[SC_USE_LS] = (ok && !over) ? n_ls : 0;
-    cnt[SC_USE_LF] = (ok && !over) ? n_lf : 0;
+    // FilterLessFlatLessCornerFeature as the reference executes it (laser_mapping.cc:340-364): the surf cloud is copied through the
+    // CORNER filter's index list [0, n_less_sharp) (:359-360).  More corners than surfs: pcl::copyPointCloud reads out of bounds.
+    const int oob = (quirks && ok && !over && n_ls > n_lf) ? 1 : 0;
+    cnt[SC_QUIRK_OOB] = oob;
+    cnt[SC_USE_LS] = (ok && !over && !oob) ? n_ls : 0;
+    cnt[SC_USE_LF] = (ok && !over && !oob) ? (quirks ? min(n_lf, n_ls) : n_lf) : 0;
     *odo_status = (!ok || over) ? 3 /*MSFL_BAD_ARG: a scan without features is not matched*/ : 0;
   }
+  // map_ls / map_lf: the clouds the MAPPING thread works with (UndistortScan makes new clouds, scan_undistortion.cc:45-62; the
+  // odometry thread's scan_last_ keeps the raw ones, laser_odometry.cc:90)
+  const int mode = imu->mode;
   if (list == 0) { if (i < n_sharp) sharp_pts[i] = full[sharp_idx[i]]; }
-  else if (list == 1) { if (i < n_ls) { const int j = ls_idx[i]; ls_pts[i] = full[j]; ls_ring[i] = ring[j]; } }
-  else if (list == 2) { if (i < n_flat) flat_pts[i] = full[flat_idx[i]]; }
-  else { if (i < n_lf) { const int j = lf_idx[i]; lf_pts[i] = full[j]; lf_ring[i] = ring[j]; } }
+  else if (list == 1) {
+    if (i < n_ls) { const int j = ls_idx[i]; const float4 p = full[j]; ls_pts[i] = p; ls_ring[i] = ring[j]; map_ls[i] = slam_map_point(p, mode, slam_preint(imu), cnt + SC_IMU_BAD); }
+  } else if (list == 2) { if (i < n_flat) flat_pts[i] = full[flat_idx[i]]; }
+  else {
+    if (i < n_lf) {
+      const int j = lf_idx[i]; const float4 p = full[j]; lf_pts[i] = p; lf_ring[i] = ring[j];
+      // UndistortScan (mode 1) runs over the whole cloud BEFORE the truncation of reference_quirks; DoUndistort (mode 2) after it,
+      // so that only the first n_less_sharp points can hit its CHECK
+      map_lf[i] = (quirks && mode == 2 && i >= n_ls) ? p : slam_map_point(p, mode, slam_preint(imu), cnt + SC_IMU_BAD);
+    }
+  }
 }
 
 // Rigid3d operator* (rigid_transform.h:105-111) and inverse() (:66-70)
@@ -95,16 +147,69 @@ __global__ void slam_map_pose_kernel(double* __restrict__ odom2map, const double
 // the pose guess passes through, exactly the reference's else-branch).
 __global__ void slam_map_gate_kernel(const int* __restrict__ n_map_c, const int* __restrict__ n_map_s, int min_c, int min_s,
                                      const int* __restrict__ m_c, const int* __restrict__ m_s, const int* __restrict__ vflag_c,
-                                     const int* __restrict__ vflag_s, const int* __restrict__ cnt, int* __restrict__ in_off,
-                                     int* __restrict__ status) {
+                                     const int* __restrict__ vflag_s, int* __restrict__ cnt, int* __restrict__ in_off,
+                                     int* __restrict__ status, const SlamImuDev* __restrict__ imu, double* __restrict__ pose_map) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int mc = max(*m_c, 0), ms = max(*m_s, 0);
   in_off[0] = 0; in_off[1] = mc; in_off[2] = 0; in_off[3] = ms; in_off[4] = 0; in_off[5] = mc + ms;
   int s = 0;
-  if (cnt[SC_STATUS] != 0 || cnt[SC_OVERFLOW] != 0) s = 3;                       // MSFL_BAD_ARG: nothing to match
+  if (cnt[SC_STATUS] != 0 || cnt[SC_OVERFLOW] != 0 || cnt[SC_QUIRK_OOB] != 0) s = 3;   // MSFL_BAD_ARG: nothing to match
+  else if (cnt[SC_IMU_BAD] != 0) {
+    // a time stamp outside the pre-integration span: the reference CHECK-aborts before anything of this scan is published;
+    // here the scan is neither matched nor inserted (the voxel filters and surrounded clouds already computed are scratch)
+    s = 3; cnt[SC_USE_LS] = 0; cnt[SC_USE_LF] = 0;
+  }
   else if (*vflag_c != 0 || *vflag_s != 0) s = 7;                                // MSFL_CAPACITY: a list did not fit the on-chip filter
   else if (!(*n_map_c > min_c && *n_map_s > min_s)) s = 2;                       // MSFL_MAP_TOO_SMALL: the gate
   *status = s;
+  // is_initialized: the matcher starts from the IMU-only pre-solve, *pose_estimate_map_scan2world = pose_j
+  // (mapping_scan_matcher.cc:57) -- only when it is called at all (gate open, laser_mapping.cc:284-311)
+  if (s == 0 && imu->mode == 2) for (int k = 0; k < 7; k++) pose_map[k] = imu->presolved[k];
+}
+
+// is_initialized branch, before the match: (dq, dp) = GetDeltaQP(preintegration, pointOri.intensity) for every down-sampled
+// feature (mapping_scan_matcher.cc:113-117,183-187) -> the arrays DeskewView takes.  blockIdx.y = list (0 corner, 1 surf).
+__global__ void __launch_bounds__(256)
+slam_delta_qp_kernel(const SlamImuDev* __restrict__ imu, const float4* __restrict__ vox_c, const float4* __restrict__ vox_s,
+                     const int* __restrict__ in_off, int cap_c, int cap_s, double* __restrict__ dq_c, double* __restrict__ dp_c,
+                     double* __restrict__ dq_s, double* __restrict__ dp_s) {
+  const int list = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = list == 0 ? min(in_off[1], cap_c) : min(in_off[3], cap_s);
+  if (i >= n) return;
+  const float4 p = list == 0 ? vox_c[i] : vox_s[i];
+  // a centroid of in-range times is in range (up to f32 rounding at the ends: clamped, where the reference would abort on an
+  // ulp); the per-point CHECK has been applied to every point of the two lists by the gather kernel
+  const PreintView pv = slam_preint(imu);
+  double dt = (double)p.w;
+  dt = fmin(fmax(dt, pv.sum_dt[0]), pv.sum_dt[pv.n - 1]);
+  const DeltaQP o = delta_qp(pv, dt);
+  double* dq = (list == 0 ? dq_c : dq_s) + 4 * (size_t)i;
+  double* dp = (list == 0 ? dp_c : dp_s) + 3 * (size_t)i;
+  dq[0] = o.q.x; dq[1] = o.q.y; dq[2] = o.q.z; dq[3] = o.q.w;
+  dp[0] = o.p.x; dp[1] = o.p.y; dp[2] = o.p.z;
+}
+
+// is_initialized branch, after the match: DoUndistort (laser_mapping.cc:197-211) on the two clouds InsertScan2Map inserts,
+//   e <- (dq(t) * e + pose_odom_scan2world_.rotation().conjugate() * (velocity_ * t - 0.5 * G * t * t) + dp(t)).cast<float>()
+// blockIdx.y = list (0 less-sharp, 1 less-flat); counts from the scan's count block (0 for a scan that is not inserted).
+__global__ void __launch_bounds__(256)
+slam_deskew_kernel(const SlamImuDev* __restrict__ imu, const double* __restrict__ pose_odom, const int* __restrict__ cnt,
+                   float4* __restrict__ map_ls, int cap_ls, float4* __restrict__ map_lf, int cap_lf) {
+  const int list = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = list == 0 ? min(cnt[SC_USE_LS], cap_ls) : min(cnt[SC_USE_LF], cap_lf);
+  if (i >= n || imu->mode != 2) return;
+  float4* pts = list == 0 ? map_ls : map_lf;
+  float4 e = pts[i];
+  const double dt = (double)e.w;
+  const DeltaQP o = delta_qp(slam_preint(imu), dt);
+  if (!o.ok) return;                       // cannot happen: the gather kernel validated every time stamp of these lists
+  quat rc; rc.x = -pose_odom[3]; rc.y = -pose_odom[4]; rc.z = -pose_odom[5]; rc.w = pose_odom[6];
+  const d3 a = quat_rotate(o.q, mk3((double)e.x, (double)e.y, (double)e.z));
+  const d3 m = mk3(imu->velocity[0] * dt - 0.5 * imu->gravity[0] * dt * dt, imu->velocity[1] * dt - 0.5 * imu->gravity[1] * dt * dt,
+                   imu->velocity[2] * dt - 0.5 * imu->gravity[2] * dt * dt);
+  const d3 b = quat_rotate(rc, m);
+  e.x = (float)(a.x + b.x + o.p.x); e.y = (float)(a.y + b.y + o.p.y); e.z = (float)(a.z + b.z + o.p.z);
+  pts[i] = e;
 }
 
 // ---- voxel filter of ONE list of more than 65 535 points (a 64-beam less-flat list), device-sized --------------------

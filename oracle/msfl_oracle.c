@@ -1445,6 +1445,15 @@ int orc_delta_qp(const double* sum_dt, const double* delta_q, const double* delt
   return 0;
 }
 
+/* GetDeltaQP(preintegration, pointOri.intensity) for every point of a cloud, as the is_initialized matcher does per feature
+   (mapping_scan_matcher.cc:113-117,183-187); returns the number of refused time stamps */
+int orc_delta_qp_cloud(const double* sum_dt, const double* delta_q, const double* delta_p, int n_samples,
+                       const orc_point* pts, int n, double* dq, double* dp) {
+  int bad = 0;
+  for (int i = 0; i < n; i++) bad += orc_delta_qp(sum_dt, delta_q, delta_p, n_samples, (double)pts[i].t, dq + 4 * i, dp + 3 * i);
+  return bad;
+}
+
 int orc_deskew_cloud(const double* sum_dt, const double* delta_q, const double* delta_p, int n_samples,
                      orc_point* pts, int n, const double rot_odom[4], const double velocity[3],
                      const double gravity[3]) {

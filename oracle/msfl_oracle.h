@@ -229,6 +229,9 @@ int orc_grid_dump(const orc_grid* g, orc_point* out, int capacity);
    makes the reference read one past the end; restated as the last sample (s = 1). */
 int orc_delta_qp(const double* sum_dt, const double* delta_q, const double* delta_p, int n_samples,
                  double dt, double q_out[4], double p_out[3]);
+/* GetDeltaQP per point of a cloud (the matcher's per-feature calls, mapping_scan_matcher.cc:113-117,183-187); returns the refused count */
+int orc_delta_qp_cloud(const double* sum_dt, const double* delta_q, const double* delta_p, int n_samples,
+                       const orc_point* pts, int n, double* dq, double* dp);
 /* laser_mapping.cc:197-211, in place; returns the number of points whose time is out of range */
 int orc_deskew_cloud(const double* sum_dt, const double* delta_q, const double* delta_p, int n_samples,
                      orc_point* pts, int n, const double rot_odom[4], const double velocity[3],

@@ -339,6 +339,15 @@ def delta_qp(sum_dt, delta_q, delta_p, dt):
     return rc, q, p
 
 
+def delta_qp_cloud(sum_dt, delta_q, delta_p, pts):
+    """GetDeltaQP at every point's relative time -> (refused, dq (n,4), dp (n,3))."""
+    sd, dq, dp = _pre(sum_dt, delta_q, delta_p)
+    pts = as_points(pts)
+    oq, op = np.zeros((len(pts), 4)), np.zeros((len(pts), 3))
+    bad = lib().orc_delta_qp_cloud(_p(sd), _p(dq), _p(dp), C.c_int(len(sd)), _p(pts), C.c_int(len(pts)), _p(oq), _p(op))
+    return bad, oq, op
+
+
 def deskew_cloud(sum_dt, delta_q, delta_p, pts, rot_odom, velocity, gravity):
     sd, dq, dp = _pre(sum_dt, delta_q, delta_p)
     pts = as_points(pts).copy()

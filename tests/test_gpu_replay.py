@@ -37,6 +37,24 @@ class OracleBackend:
     def new_grids(self):
         return self.o.HybridGrid(3.0, 0.2), self.o.HybridGrid(3.0, 0.4)
 
+    # ---- the IMU branches of LaserMapping::Run (pre = (sum_dt, delta_q, delta_p))
+    def undistort(self, pre, pts):
+        bad, out = self.o.undistort_cloud(*pre, pts)                       # scan_undistortion.cc:5-19
+        assert bad == 0
+        return out
+
+    def deskew(self, pre, pts, rot_odom, velocity, gravity):
+        bad, out = self.o.deskew_cloud(*pre, pts, rot_odom, velocity, gravity)   # laser_mapping.cc:197-211
+        assert bad == 0
+        return out
+
+    def scan2map_deskew(self, mc, ms, corner, surf, pre, velocity, gravity, pose):
+        bad_c, cdq, cdp = self.o.delta_qp_cloud(*pre, corner)              # mapping_scan_matcher.cc:113-117
+        bad_s, sdq, sdp = self.o.delta_qp_cloud(*pre, surf)                # :183-187
+        assert bad_c == 0 and bad_s == 0
+        rc, p, _ = self.o.match_scan2map_deskew(mc, ms, corner, surf, cdq, cdp, sdq, sdp, velocity, gravity, pose)
+        return p
+
 
 class OracleBackendRigid3d(OracleBackend):
     """The oracle-driven loop with the reference's own Rigid3d algebra (rigid_transform.h:78-82,105-111,131-137) instead of
@@ -106,6 +124,108 @@ def test_device_resident_slam_step_matches_the_oracle_loop_over_300_scans(oracle
         ref = getattr(test_device_resident_slam_step_matches_the_oracle_loop_over_300_scans, "sync_poses", None)
         if ref is not None:
             assert np.array_equal(ref, est_g)
+
+
+@pytest.mark.parametrize("variant", ["quirks", "imu", "quirks+imu"])
+def test_slam_step_runs_what_laser_mapping_run_runs(oracle, variant):
+    """LaserMapping::Run as the reference executes it: `reference_quirks` (FilterLessFlatLessCornerFeature cuts the surf cloud
+    to its first n_less_sharp points, laser_mapping.cc:186,340-364: that cloud is filtered, matched AND inserted) and the
+    per-scan IMU inputs (UndistortScan before the match for the first 50 scans, :170-176; from scan 50 on the is_initialized
+    matcher branch from the pre-solved pose with Deskew factors and DoUndistort before the insert, :197-211).  300 scans
+    through msfl_slam_add_scan_imu, pipelined, against the oracle-driven loop doing the same on the CPU: every pose within
+    1e-6 m / 1e-6 rad, the same final map stores.  The synchronous form of the first 80 scans must equal the pipelined one
+    bit for bit (both branches and the switch are inside)."""
+    n = 300
+    quirks, with_imu = "quirks" in variant, "imu" in variant
+    world = synth.World(ground_half=45.0)
+    truth = rp.trajectory(n)
+    imu = rp.synthetic_imu(truth, switch_at=50) if with_imu else None
+    maps_o, maps_g = {}, {}
+    est_o, _ = rp.run(OracleBackendRigid3d(oracle), world, truth, maps_out=maps_o, quirks=quirks, imu=imu)
+    est_g, recs, _ = rp.run_slam(world, truth, pipelined=True, maps_out=maps_g, quirks=quirks, imu=imu)
+    d = np.array([synth.pose_error(a, b) for a, b in zip(est_g, est_o)])
+    assert d[:, 0].max() < 1e-6 and d[:, 1].max() < 1e-6, (d.max(axis=0), int(d[:, 0].argmax()))
+    assert all(r.status_extract == 0 and r.status_imu == 0 and r.status_insert == 0 for r in recs)
+    assert sum(1 for r in recs if r.status_mapping != 0) <= 2
+    for k in ("corner", "surf"):
+        assert maps_g[k].shape == maps_o[k].shape, (k, maps_g[k].shape, maps_o[k].shape)
+        assert np.abs(maps_g[k] - maps_o[k]).max() < 1e-4
+    if quirks:      # the truncated surf list is what the mapping thread sees: n_surf_ds is the filter of n_less_sharp points only
+        assert all(r.n_surf_ds <= r.n_less_sharp for r in recs)
+        assert recs[-1].grid_surf[0] < 0.5 * 40000     # far fewer surf map points than the full lists leave (~40 k)
+    if with_imu:    # the trajectory is not the LiDAR-only one: the IMU passes really act
+        est_plain, _ = _oracle_loop(oracle, world, truth, n) if not quirks else (None, None)
+        if est_plain is not None:
+            assert np.abs(est_plain[60:, :3] - est_o[60:, :3]).max() > 1e-4
+    # tracking quality stays that of LOAM on this drive
+    assert rp.ate(est_g, truth) < 0.35
+    est_s, _, _ = rp.run_slam(world, truth[:80], pipelined=False, quirks=quirks, imu=imu[:80] if imu else None)
+    assert np.array_equal(est_s, est_g[:80])
+
+
+def test_slam_imu_refusals_and_quirk_out_of_bounds(oracle):
+    """The reference's CHECK failures and its out-of-bounds read become per-scan statuses: a time stamp outside the
+    pre-integration span (scan_undistortion.cc:26-30) -> status_imu = status_mapping = MSFL_BAD_ARG, the scan is neither
+    matched nor inserted and the pipeline carries on; reference_quirks with more less-sharp than less-flat points ->
+    status_mapping = MSFL_BAD_ARG; argument errors (too many samples, decreasing sum_dt) are refused before anything is
+    enqueued."""
+    from msf_loam_amd import capi
+    world = synth.World(ground_half=45.0)
+    truth = rp.trajectory(6)
+    scans = [synth.make_scan(world, truth[k], synth.SEED + 5000 + k) for k in range(6)]
+    imu = rp.synthetic_imu(truth, switch_at=3)
+    slam = capi.Slam(0, max_scan_points=max(len(p) for p, _ in scans), max_rings=16, pose_odom2map=truth[0])
+    r0 = slam.add_scan(*scans[0], imu=imu[0])
+    r1 = slam.add_scan(*scans[1], imu=imu[1])
+    assert r0.status_imu == 0 and r1.status_imu == 0 and r1.status_mapping in (0, capi.MAP_TOO_SMALL)
+    short = dict(imu[2]); short["sum_dt"] = np.linspace(0.0, 0.05, 45)       # the scan spans 0.1 s: half of its points fall outside
+    r2 = slam.add_scan(*scans[2], imu=short)
+    assert r2.status_imu == capi.BAD_ARG and r2.status_mapping == capi.BAD_ARG and r2.status_extract == 0
+    assert list(r2.grid_corner)[:2] == list(r1.grid_corner)[:2] and list(r2.grid_surf)[:2] == list(r1.grid_surf)[:2]   # nothing inserted
+    r3 = slam.add_scan(*scans[3], imu=imu[3])                                 # is_initialized, good span: carries on
+    assert r3.status_imu == 0 and r3.status_mapping == 0 and r3.grid_surf[0] > r2.grid_surf[0]
+    neg = dict(imu[4]); neg["is_initialized"] = False; neg["sum_dt"] = np.linspace(0.02, 0.13, 45)   # times below front()
+    assert slam.add_scan(*scans[4], imu=neg).status_imu == capi.BAD_ARG
+    with pytest.raises(capi.MsflError) as e:
+        many = dict(imu[5]); many["sum_dt"] = np.linspace(0, 0.11, 3000); many["delta_q"] = np.tile([0, 0, 0, 1.0], (3000, 1)); many["delta_p"] = np.zeros((3000, 3))
+        slam.add_scan(*scans[5], imu=many)
+    assert e.value.status == capi.CAPACITY
+    with pytest.raises(capi.MsflError) as e:
+        dec = dict(imu[5]); dec["sum_dt"] = np.linspace(0.11, 0.0, 45)
+        slam.add_scan(*scans[5], imu=dec)
+    assert e.value.status == capi.BAD_ARG
+    r5 = slam.add_scan(*scans[5], imu=imu[5])                                 # refused calls enqueued nothing: not poisoned
+    assert r5.status_imu == 0 and r5.scan_index == 5
+    slam.close()
+    # reference_quirks: a scan with MORE less-sharp than less-flat points (jagged ranges: every sector fills its 20 corner picks
+    # and nothing is left flat or unlabelled) -- the reference's copyPointCloud would read out of bounds
+    rng = np.random.default_rng(3)
+    m = 48
+    az = np.linspace(0, 2 * np.pi, m, endpoint=False)
+    jp, jr = [], []
+    for b in range(16):
+        el, rg = np.deg2rad(-15 + 2 * b), rng.uniform(5, 30, m)
+        jp.append(np.c_[rg * np.cos(el) * np.cos(-az), rg * np.cos(el) * np.sin(-az), rg * np.sin(el), np.zeros(m)])
+        jr.append(np.full(m, b))
+    jp, jr = np.concatenate(jp).astype(np.float32), np.concatenate(jr).astype(np.uint16)
+    order = np.lexsort((jr, np.tile(np.arange(m), 16)))
+    jp, jr = jp[order], jr[order]
+    fo = oracle.extract_features(jp, jr)
+    assert len(fo["less_sharp"]) > len(fo["less_flat"])                       # the premise
+    pts, ring = scans[0]
+    slam = capi.Slam(0, max_scan_points=len(pts), max_rings=16, pose_odom2map=truth[0], reference_quirks=1)
+    a = slam.add_scan(pts, ring)
+    assert a.status_mapping in (0, capi.MAP_TOO_SMALL) and 0 < a.n_surf_ds <= a.n_less_sharp
+    b = slam.add_scan(jp, jr)
+    assert b.status_extract == 0 and b.n_less_sharp == len(fo["less_sharp"]) and b.n_less_flat == len(fo["less_flat"])
+    assert b.status_mapping == capi.BAD_ARG and b.status_imu == 0 and b.n_corner_ds == 0 and b.n_surf_ds == 0
+    assert list(b.grid_corner)[:2] == list(a.grid_corner)[:2] and list(b.grid_surf)[:2] == list(a.grid_surf)[:2]   # not inserted
+    c = slam.add_scan(pts, ring)                                              # the pipeline carries on
+    assert c.status_mapping == 0 and c.grid_surf[0] >= a.grid_surf[0]
+    slam.close()
+    plain = capi.Slam(0, max_scan_points=len(pts), max_rings=16, pose_odom2map=truth[0])
+    assert plain.add_scan(jp, jr).status_mapping in (0, capi.MAP_TOO_SMALL)   # without the quirk the same scan is an ordinary one
+    plain.close()
 
 
 def _figure_eight(n, step_scale):

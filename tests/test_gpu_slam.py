@@ -72,7 +72,9 @@ def test_bad_scans_become_statuses_and_the_pipeline_goes_on():
     pts, ring = scans[2]
     bad_ring = ring.copy(); bad_ring[100] = 200
     r = s.add_scan(pts, bad_ring)
-    assert r.status_extract == capi.BAD_RING and r.status_mapping == capi.BAD_ARG and r.odometry.status == 0
+    # a scan that is not matched at all is not a successful MatchScan2Scan: the odometry record says so too
+    assert r.status_extract == capi.BAD_RING and r.status_mapping == capi.BAD_ARG and r.odometry.status == capi.BAD_ARG
+    assert list(r.odometry.lm_iterations) == [0, 0] and r.status_imu == 0 and r.status_insert == 0
     assert np.array_equal(np.array(r.pose_odom[:]), np.array(good[1].pose_odom[:]))        # the chain is left where it was
     assert list(r.grid_surf)[:2] == list(good[1].grid_surf)[:2]                            # nothing inserted
     nan = pts.copy(); nan[:, :3] = np.nan
