@@ -60,7 +60,7 @@ def build_inputs(B, map_points, seed_offset, extractor=None, scan_ids=None, with
         corner.append(c); surf.append(s)
         co.append(co[-1] + len(c)); so.append(so[-1] + len(s))
     z = np.zeros((0, 4), np.float32)
-    return dict(map_corner=map_corner, map_surf=map_surf, truth=poses, guesses=guesses,
+    return dict(map_corner=map_corner, map_surf=map_surf, truth=poses, guesses=guesses, raw=raw, world=world,
                 corner=np.concatenate(corner) if corner else z, surf=np.concatenate(surf) if surf else z,
                 corner_off=np.array(co, np.int32), surf_off=np.array(so, np.int32))
 
@@ -248,6 +248,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: leave the per-kernel HIP events off during the timed steps (roofline.achieved is then 0)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive leg (value_incl_h2d)")
+    ap.add_argument("--no-stages", action="store_true", help="skip the `stages` leg (extraction, voxel filters, scan-to-scan, raw-scan pipeline, SLAM step)")
+    ap.add_argument("--stage-slam-scans", type=int, default=100, help="scans of the SLAM-step replay in `stages` (0 disables it)")
     ap.add_argument("--features", choices=["product", "direct"], default="product",
                     help="product: features from the GPU extraction + voxel kernels; direct: from ray-cast hit kinds")
     args = ap.parse_args()
@@ -299,9 +301,12 @@ def main():
     else:
         inp = build_inputs(args.scans, args.map_points, rank, extractor, with_map=(rank == 0))
     B = len(inp["guesses"])
-    if use_dist and world_size > 1:
+    # MSFL_BENCH_FORCE_COLLECTIVES=1: run the map broadcast and the ragged gather even in a one-rank group, so that a 1-GPU box
+    # executes every RCCL call of the N-GPU path (init with device_id, broadcast, all_gather_into_tensor on device tensors)
+    force_coll = use_dist and os.environ.get("MSFL_BENCH_FORCE_COLLECTIVES") == "1"
+    if use_dist and (world_size > 1 or force_coll):
         bdev = torch.device("cpu") if shared_gpu else dev
-        mc_t, ms_t = mdist.broadcast_map(inp["map_corner"], inp["map_surf"], src=0, device=bdev)
+        mc_t, ms_t = mdist.broadcast_map(inp["map_corner"], inp["map_surf"], src=0, device=bdev, force=force_coll)
         inp["map_corner"], inp["map_surf"] = mc_t.cpu().numpy(), ms_t.cpu().numpy()
     t_prep = time.perf_counter() - t_prep
 
@@ -387,9 +392,9 @@ def main():
         # every rank's block back in scan order (one more gather, outside the timed region): the job's result must not
         # depend on how many ranks shared it
         import hashlib
-        if use_dist and world_size > 1:
+        if use_dist and (world_size > 1 or force_coll):
             t_p = torch.from_numpy(poses_gpu).to(dev if not shared_gpu else "cpu"); t_s = torch.from_numpy(status_gpu).to(dev if not shared_gpu else "cpu")
-            all_p, all_s = mdist.gather_ragged(t_p, t_s, total_scans)
+            all_p, all_s = mdist.gather_ragged(t_p, t_s, total_scans, force=force_coll)
             all_p = all_p.cpu().numpy()
         else:
             all_p = poses_gpu
@@ -460,7 +465,8 @@ def main():
         }
         if strong:
             out["poses_sha1"] = poses_sha1
-            out["config"]["map_source"] = "built on rank 0, broadcast over the process group" if world_size > 1 else "built on rank 0"
+            out["config"]["map_source"] = "built on rank 0, broadcast over the process group" if (world_size > 1 or force_coll) else "built on rank 0"
+            out["config"]["process_group_backend"] = dist.get_backend() if use_dist else None
         out["value_incl_h2d"] = None               # N=1 only: the host-buffer call is a separate, untimed-for-`value` leg
         if world_size == 1 and not args.no_h2d:
             v, ms, nbytes = host_buffer_rate(h, inp, B)
@@ -495,6 +501,21 @@ def main():
                 t["Optimization twice"] = t["Data association"] + t["Solver time"]
             out["stages_MAP"] = {"cpu_port_ms_per_registration_1_thread": cpu,
                                  "gpu_ms_per_batch": gpu, "gpu_us_per_registration": {n_: 1e3 * v / B for n_, v in gpu.items()}}
+        # the other stages of the hot path (the raw-scan pipeline, configs[2]'s per-scan step): measured on
+        # this batch's own raw scans AFTER everything that feeds `value`, each spot-checked against the oracle (checker use only)
+        out["stages"] = None
+        if world_size == 1 and not args.no_stages and not strong and inp.get("raw"):
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_stages
+            checker = None
+            if args.cpu_sample > 0:
+                from oracle import oracle as checker_mod
+                checker_mod.build()
+                checker = checker_mod
+            t_st = time.perf_counter()
+            out["stages"] = bench_stages.measure(inp["raw"], inp["world"], inp["map_corner"], inp["map_surf"], inp["truth"], inp["guesses"],
+                                                 device=local_rank, slam_scans=args.stage_slam_scans, checker=checker)
+            out["stages"]["wall_s"] = time.perf_counter() - t_st
         print(json.dumps(out))
     h.close()
     if use_dist:

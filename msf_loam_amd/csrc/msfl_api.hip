@@ -18,6 +18,10 @@
 #include <string>
 #include <vector>
 
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "../../include/msfl_c_api.h"
 #include "msfl_kernels.cuh"
 #include "msfl_extract.cuh"

@@ -20,9 +20,10 @@ def shard_offsets(off, lo, hi):
     return (off[lo:hi + 1] - off[lo]).astype(np.int32), (int(off[lo]), int(off[hi]))
 
 
-def broadcast_map(corner, surf, src=0, device=None):
-    """Replicate the local map (float32 (n,4) arrays) from `src` to every rank."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def broadcast_map(corner, surf, src=0, device=None, force=False):
+    """Replicate the local map (float32 (n,4) arrays) from `src` to every rank.
+    force: run the collectives even in a one-rank group (the 1-rank RCCL dry run of tests/test_gpu_bench_ranks.py)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return corner, surf
     dev = device or torch.device("cpu")
     rank = dist.get_rank()
@@ -95,10 +96,10 @@ class PoseGather:
             torch.cuda.current_stream(self.send.device).wait_stream(self._side)
 
 
-def gather_ragged(poses, status, n_total):
-    """Gather block-partitioned results of uneven shards back into scan order on every rank."""
+def gather_ragged(poses, status, n_total, force=False):
+    """Gather block-partitioned results of uneven shards back into scan order on every rank (force: also in a one-rank group)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return poses, status
     dev = poses.device
     cap = (n_total + world - 1) // world

@@ -56,3 +56,31 @@ def test_strong_scaling_shards_one_job_and_broadcasts_the_map():
         assert abs(d["value"] - 65 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert two["config"]["scans_per_gpu"] == 33 and "broadcast" in two["config"]["map_source"]
     assert one["poses_sha1"] == two["poses_sha1"], "the job's poses must not depend on the number of ranks"
+
+
+@pytest.mark.gpu
+def test_one_rank_over_rccl_executes_every_collective_of_the_multi_gpu_path():
+    """The first 8-GPU run must not be the first RCCL run.  One rank under torch.distributed.run WITHOUT the shared-GPU hook:
+    init_process_group("nccl", device_id=...) (nccl IS RCCL on ROCm), the map broadcast and the ragged pose gather forced on
+    (MSFL_BENCH_FORCE_COLLECTIVES=1), the per-step all_gather_into_tensor on device tensors and the timing all_gather -- and
+    the job's poses equal, bit for bit, those of the plain single-process run."""
+    def run(launched, port=29561):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "MSFL_BENCH_SHARED_GPU", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        if launched:
+            env["MSFL_BENCH_FORCE_COLLECTIVES"] = "1"
+        launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port)] if launched else [sys.executable]
+        cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--scaling", "strong",
+                          "--total-scans", "64", "--cpu-sample", "0", "--no-h2d", "--no-stages"]
+        out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        return json.loads(lines[0])
+    rccl, plain = run(True), run(False)
+    assert rccl["rccl_ranks"] == 1 and rccl["n_gpus"] == 1 and rccl["n_failed"] == 0
+    assert rccl["config"]["process_group_backend"] == "nccl" and "broadcast" in rccl["config"]["map_source"]
+    assert plain["config"]["process_group_backend"] is None
+    assert rccl["poses_sha1"] == plain["poses_sha1"]
