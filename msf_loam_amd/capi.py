@@ -67,7 +67,8 @@ class Timing(C.Structure):
                 ("launches_index", C.c_int), ("ms_index", C.c_double),
                 ("launches_extract", C.c_int), ("ms_extract", C.c_double),
                 ("launches_odom", C.c_int), ("ms_odom", C.c_double),
-                ("launches_fit", C.c_int), ("ms_fit", C.c_double), ("knn_candidates", C.c_ulonglong)]
+                ("launches_fit", C.c_int), ("ms_fit", C.c_double), ("knn_candidates", C.c_ulonglong), ("knn_candidates_seeded", C.c_ulonglong),
+                ("launches_assoc_seeded", C.c_int), ("ms_assoc_seeded", C.c_double)]
 
 
 class Deskew(C.Structure):

@@ -115,7 +115,7 @@ struct MapIndex {
   int n_input = 0;    // points handed to msfl_set_map
 };
 
-enum TimerClass { T_ASSOC = 0, T_SOLVE, T_INDEX, T_EXTRACT, T_ODOM, T_FIT, T_COUNT };
+enum TimerClass { T_ASSOC = 0, T_SOLVE, T_INDEX, T_EXTRACT, T_ODOM, T_FIT, T_ASSOC_SEEDED /* a subset of T_ASSOC */, T_COUNT };
 
 struct TimedSpan { hipEvent_t a, b; int cls; };
 
@@ -136,6 +136,7 @@ struct msfl_handle_s {
   bool voxel_force_global = false;        // MSFL_VOXEL_GLOBAL=1: the batched voxel filter keeps the device-wide radix-sort form (A/B testing)
   long long odom_wave_max_targets = -1;   // MSFL_ODOM_WAVE_MAX_TARGETS: previous-scan points up to which a small batch takes the one-wavefront-per-query kernel (default 4096 per pair)
   bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)
+  bool knn_seed = true;                   // MSFL_KNN_SEED=0: the second outer iteration's 5-NN search starts from the gate like the first (A/B)
   int knn_form = 0;                       // MSFL_KNN_FORM: 0 auto (row-parallel latency form for launches of <= kKnnRowsMaxRecords queries),
                                           // 1 "lane" (one lane per query always), 2 "rows" (row-parallel always); results are identical
 
@@ -187,7 +188,7 @@ hipEvent_t get_event(msfl_handle* h) {
 
 struct ScopedTimer {
   msfl_handle* h; TimedSpan s{}; bool on;
-  ScopedTimer(msfl_handle* h_, int cls) : h(h_), on(h_->timing == 1 || h_->timing == 3 || (h_->timing == 2 && cls == T_ASSOC)) {
+  ScopedTimer(msfl_handle* h_, int cls) : h(h_), on(h_->timing == 1 || h_->timing == 3 || (h_->timing == 2 && (cls == T_ASSOC || cls == T_ASSOC_SEEDED))) {
     if (on) { s.a = get_event(h); s.b = get_event(h); s.cls = cls; (void)hipEventRecord(s.a, h->stream); }
   }
   ~ScopedTimer() {
@@ -199,7 +200,10 @@ void collect_timing(msfl_handle* h) {
   for (auto& s : h->spans) {
     (void)hipEventSynchronize(s.b);
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { h->t_ms[s.cls] += ms; h->t_n[s.cls]++; }
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      h->t_ms[s.cls] += ms; h->t_n[s.cls]++;
+      if (s.cls == T_ASSOC_SEEDED) { h->t_ms[T_ASSOC] += ms; h->t_n[T_ASSOC]++; }
+    }
     h->free_events.push_back(s.a); h->free_events.push_back(s.b);
   }
   h->spans.clear();
@@ -300,8 +304,11 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi, 
 
 // one data-association pass = kNN kernel + fit kernel
 // (records [rec_begin, rec_end) of the batch; rec_end < 0: all of them)
+// seed: `nn` still holds this batch's neighbours from the previous outer iteration (same records, same map index): the 5-NN search
+// starts from the bound they give (knn5_seed_bound; exact, MSFL_KNN_SEED=0 switches it off for A/B)
 void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_poses, const int* d_status, bool deskew,
-                    const DeskewView& dv, int n_rec, double* full = nullptr, int rec_begin = 0, int rec_end = -1) {
+                    const DeskewView& dv, int n_rec, double* full = nullptr, int rec_begin = 0, int rec_end = -1, bool seed = false) {
+  seed = seed && h->knn_seed;
   hipStream_t st = h->stream;
   int* nn = h->nn.as<int>();
   BatchView bv = bv_all;
@@ -309,7 +316,7 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
   if (n_rec <= 0) return;
   const dim3 grid(div_up(n_rec, kAssocBlock)), block(kAssocBlock);
   {
-    ScopedTimer timer(h, T_ASSOC);
+    ScopedTimer timer(h, seed ? T_ASSOC_SEEDED : T_ASSOC);
     if (h->timing == 3) {
       unsigned long long* cnt = h->knn_count.as<unsigned long long>();
       if (deskew)
@@ -318,6 +325,12 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
                            (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
                            (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
                            h->prm.map_knn_max_sq_dist, dv, nn, cnt);
+      else if (seed)
+        hipLaunchKernelGGL((knn5_scan2map_kernel<false, true, true>), grid, block, 0, st, bv, d_poses, d_status,
+                           (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                           (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                           (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
+                           h->prm.map_knn_max_sq_dist, dv, nn, cnt + 1);
       else
         hipLaunchKernelGGL((knn5_scan2map_kernel<false, true>), grid, block, 0, st, bv, d_poses, d_status,
                            (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
@@ -327,10 +340,16 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
     } else if (!deskew && !bv.dyn && rec_end < 0 && n_rec >= 65536) {       // a whole large batch: one body per feature kind (-2 %)
       const int n_s = bv.n_surf_total, n_c = n_rec - n_s;
       const int edge_blocks = div_up(n_c, kAssocBlock), plane_blocks = div_up(n_s, kAssocBlock);
-      hipLaunchKernelGGL(knn5_scan2map_split_kernel, dim3(edge_blocks + plane_blocks), block, 0, st, bv, d_poses, d_status,
-                         (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
-                         (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
-                         (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(), h->prm.map_knn_max_sq_dist, nn, edge_blocks);
+      if (seed)
+        hipLaunchKernelGGL(knn5_scan2map_split_kernel<true>, dim3(edge_blocks + plane_blocks), block, 0, st, bv, d_poses, d_status,
+                           (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                           (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                           (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(), h->prm.map_knn_max_sq_dist, nn, edge_blocks);
+      else
+        hipLaunchKernelGGL(knn5_scan2map_split_kernel<false>, dim3(edge_blocks + plane_blocks), block, 0, st, bv, d_poses, d_status,
+                           (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                           (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                           (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(), h->prm.map_knn_max_sq_dist, nn, edge_blocks);
     } else if (!deskew && (h->knn_form == 2 || (h->knn_form == 0 && n_rec <= kKnnRowsMaxRecords)))
       hipLaunchKernelGGL(knn5_scan2map_rows_kernel, dim3(div_up(n_rec, kKnnRowsBlock / kKnnRowLanes)), dim3(kKnnRowsBlock), 0, st, bv, d_poses, d_status,
                          (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
@@ -338,6 +357,12 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
                          (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(), h->prm.map_knn_max_sq_dist, nn);
     else if (deskew)
       hipLaunchKernelGGL(knn5_scan2map_kernel<true>, grid, block, 0, st, bv, d_poses, d_status,
+                         (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
+                         (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
+                         (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
+                         h->prm.map_knn_max_sq_dist, dv, nn);
+    else if (seed)
+      hipLaunchKernelGGL((knn5_scan2map_kernel<false, false, true>), grid, block, 0, st, bv, d_poses, d_status,
                          (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
                          (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
                          (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
@@ -416,7 +441,7 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
         s_launch_assoc(h, bv, d_poses, d_status, deskew != nullptr, dv, n_rec, nullptr, offs[2 * (B + 1) + chunk_b[c]], offs[2 * (B + 1) + chunk_b[c + 1]]);
       }
     } else if (n_rec > 0) {
-      s_launch_assoc(h, bv, d_poses, d_status, deskew != nullptr, dv, n_rec);
+      s_launch_assoc(h, bv, d_poses, d_status, deskew != nullptr, dv, n_rec, nullptr, 0, -1, it > 0);
     }
     {
       ScopedTimer timer(h, T_SOLVE);
@@ -510,6 +535,7 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
   if (const char* e = std::getenv("MSFL_H2D_CHUNK_SCANS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_chunk_scans = c; }
   if (const char* e = std::getenv("MSFL_H2D_SUB_CHUNKS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_sub_chunks = c; }
   if (const char* e = std::getenv("MSFL_ODOM_BRUTE")) h->odom_force_brute = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MSFL_KNN_SEED")) h->knn_seed = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSFL_KNN_FORM")) h->knn_form = !std::strcmp(e, "lane") ? 1 : !std::strcmp(e, "rows") ? 2 : 0;
   if (const char* e = std::getenv("MSFL_ODOM_WAVE_MAX_TARGETS")) h->odom_wave_max_targets = std::atoll(e);
   if (const char* e = std::getenv("MSFL_VOXEL_GLOBAL")) h->voxel_force_global = std::atoi(e) != 0;
@@ -596,8 +622,8 @@ msfl_status msfl_set_timing(msfl_handle* h, int enabled) {
   msfl_status s = enter(h); if (s) return s;
   h->timing = enabled < 0 ? 0 : (enabled > 3 ? 1 : enabled);
   if (h->timing == 3 && !h->knn_count.p) {
-    HIPCHK(h, h->knn_count.reserve(sizeof(unsigned long long)));
-    HIPCHK(h, hipMemsetAsync(h->knn_count.p, 0, sizeof(unsigned long long), h->stream));
+    HIPCHK(h, h->knn_count.reserve(2 * sizeof(unsigned long long)));     // [first-pass launches, seeded launches]
+    HIPCHK(h, hipMemsetAsync(h->knn_count.p, 0, 2 * sizeof(unsigned long long), h->stream));
   }
   return MSFL_OK;
 }
@@ -613,10 +639,13 @@ msfl_status msfl_get_timing(msfl_handle* h, msfl_timing* out, int reset) {
   out->launches_extract = h->t_n[T_EXTRACT]; out->ms_extract = h->t_ms[T_EXTRACT];
   out->launches_odom = h->t_n[T_ODOM];       out->ms_odom = h->t_ms[T_ODOM];
   out->launches_fit = h->t_n[T_FIT];         out->ms_fit = h->t_ms[T_FIT];
-  out->knn_candidates = 0;
+  out->launches_assoc_seeded = h->t_n[T_ASSOC_SEEDED]; out->ms_assoc_seeded = h->t_ms[T_ASSOC_SEEDED];
+  out->knn_candidates = 0; out->knn_candidates_seeded = 0;
   if (h->knn_count.p) {
-    HIPCHK(h, hipMemcpy(&out->knn_candidates, h->knn_count.p, sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (reset) HIPCHK(h, hipMemset(h->knn_count.p, 0, sizeof(unsigned long long)));
+    unsigned long long c2[2] = {0, 0};
+    HIPCHK(h, hipMemcpy(c2, h->knn_count.p, sizeof(c2), hipMemcpyDeviceToHost));
+    out->knn_candidates = c2[0]; out->knn_candidates_seeded = c2[1];
+    if (reset) HIPCHK(h, hipMemset(h->knn_count.p, 0, sizeof(c2)));
   }
   if (reset) for (int i = 0; i < T_COUNT; i++) { h->t_ms[i] = 0; h->t_n[i] = 0; }
   return MSFL_OK;

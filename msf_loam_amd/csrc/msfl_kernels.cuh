@@ -277,6 +277,8 @@ __device__ __forceinline__ float axis_gap(float u, int c) {
   return fmaxf(g - 1e-3f, 0.0f);
 }
 
+// max_sq_dist here is the INITIAL bound of the search: the acceptance gate, or (second outer iteration) something tighter
+// that five real map points are known to meet (knn5_seed_bound).
 __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __restrict__ sorted,
                                           const int* __restrict__ cell_start, float3 q, float max_sq_dist, Top5& t,
                                           int& n_cand) {      // n_cand: candidates evaluated (dead code unless the caller reads it)
@@ -364,6 +366,27 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
     if (a > b) continue;                      // only near the grid border: every remaining cell is out of reach
     scan(row, a, b);
   }
+}
+
+// Second outer iteration (mapping_scan_matcher.cc:75: the association loop runs kOptimalNum = 2 times on the same clouds): the five
+// neighbours the first pass found for this feature (positions in the sorted map, still in `nn`) are five DISTINCT real map
+// points, so the largest of their f32 distances to the re-transformed query is an upper bound of the new 5th-nearest
+// distance.  Starting the top-5 from (min(gate, that distance), 0xffffffff) sentinels trims rows and x-cells from the first
+// row on and the result is still the exact top-5 by (distance, index): a candidate AT the bound compares below the sentinel's
+// index word, and at least five real candidates are within the bound.  A feature the first pass rejected keeps the gate.
+__device__ __forceinline__ float knn5_seed_bound(const float4* __restrict__ sorted, const int* __restrict__ prev, float3 q, float gate) {
+  const int p0 = prev[0];
+  if (p0 < 0) return gate;
+  const int p1 = prev[1], p2 = prev[2], p3 = prev[3], p4 = prev[4];
+  const float4 m0 = sorted[p0], m1 = sorted[p1], m2 = sorted[p2], m3 = sorted[p3], m4 = sorted[p4];
+  const msfl_f2 qxy = {q.x, q.y};
+  float m = l2_simple_pk(m0, qxy, q.z);
+  float d;
+  d = l2_simple_pk(m1, qxy, q.z); m = d > m ? d : m;
+  d = l2_simple_pk(m2, qxy, q.z); m = d > m ? d : m;
+  d = l2_simple_pk(m3, qxy, q.z); m = d > m ? d : m;
+  d = l2_simple_pk(m4, qxy, q.z); m = d > m ? d : m;
+  return m < gate ? m : gate;         // a NaN distance (non-finite query) leaves the gate in place
 }
 
 struct FitOut { d3 C, N; bool ok; };
@@ -485,7 +508,7 @@ struct DeskewView {
 #define MSFL_ASSOC_BLOCK 64
 #endif
 constexpr int kAssocBlock = MSFL_ASSOC_BLOCK;      // threads per workgroup of the 5-NN and fit kernels
-template <bool DESKEW, bool COUNT = false>
+template <bool DESKEW, bool COUNT = false, bool SEED = false>
 __global__ void __launch_bounds__(kAssocBlock)
 knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
                      const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
@@ -527,8 +550,9 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   }
   Top5 t;
   int n_cand = 0;
-  if (is_edge) { const GridDesc gc = *gcp; knn5_grid(gc, map_c, cs_c, q, max_sq_dist, t, n_cand); }
-  else { const GridDesc gs = *gsp; knn5_grid(gs, map_s, cs_s, q, max_sq_dist, t, n_cand); }
+  const float bound = SEED ? knn5_seed_bound(is_edge ? map_c : map_s, out, q, max_sq_dist) : max_sq_dist;
+  if (is_edge) { const GridDesc gc = *gcp; knn5_grid(gc, map_c, cs_c, q, bound, t, n_cand); }
+  else { const GridDesc gs = *gsp; knn5_grid(gs, map_s, cs_s, q, bound, t, n_cand); }
   if (COUNT) {                                                  // one atomic per wavefront: sum over the lanes still here
     const unsigned long long act = __ballot(1);
     unsigned long long m = act;
@@ -549,7 +573,7 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
 
 // K4a for a whole large batch of the plain branch: blocks [0, edge_blocks) serve the corner features (corner map index), the rest
 // the surf features, so that a wavefront never holds both kinds and each body knows its map at compile time.
-template <bool EDGE>
+template <bool EDGE, bool SEED>
 __device__ __forceinline__ void knn5_one_kind(const BatchView& bv, const double* __restrict__ poses, const int* __restrict__ status,
                                               const GridDesc* __restrict__ gp, const float4* __restrict__ map, const int* __restrict__ cs,
                                               const int* __restrict__ po, float max_sq_dist, int* __restrict__ nn, int block) {
@@ -567,7 +591,7 @@ __device__ __forceinline__ void knn5_one_kind(const BatchView& bv, const double*
   Top5 t;
   int n_cand = 0;
   const GridDesc gd = *gp;
-  knn5_grid(gd, map, cs, q, max_sq_dist, t, n_cand);
+  knn5_grid(gd, map, cs, q, SEED ? knn5_seed_bound(map, out, q, max_sq_dist) : max_sq_dist, t, n_cand);
   if ((unsigned int)t.k4 != 0xffffffffu && (double)top5_d4(t) < (double)max_sq_dist) {      // :128 / :198
     out[0] = po[(unsigned int)t.k0]; out[1] = po[(unsigned int)t.k1]; out[2] = po[(unsigned int)t.k2];
     out[3] = po[(unsigned int)t.k3]; out[4] = po[(unsigned int)t.k4];       // nearest first
@@ -575,13 +599,14 @@ __device__ __forceinline__ void knn5_one_kind(const BatchView& bv, const double*
     out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1;
   }
 }
+template <bool SEED>
 __global__ void __launch_bounds__(kAssocBlock)
 knn5_scan2map_split_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
                            const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
                            const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
                            const int* __restrict__ pos_c, const int* __restrict__ pos_s, float max_sq_dist, int* __restrict__ nn, int edge_blocks) {
-  if ((int)blockIdx.x < edge_blocks) knn5_one_kind<true>(bv, poses, status, gcp, map_c, cs_c, pos_c, max_sq_dist, nn, (int)blockIdx.x);
-  else knn5_one_kind<false>(bv, poses, status, gsp, map_s, cs_s, pos_s, max_sq_dist, nn, (int)blockIdx.x - edge_blocks);
+  if ((int)blockIdx.x < edge_blocks) knn5_one_kind<true, SEED>(bv, poses, status, gcp, map_c, cs_c, pos_c, max_sq_dist, nn, (int)blockIdx.x);
+  else knn5_one_kind<false, SEED>(bv, poses, status, gsp, map_s, cs_s, pos_s, max_sq_dist, nn, (int)blockIdx.x - edge_blocks);
 }
 
 // K4a, latency form: the same exact 5-NN for a launch too small to fill the machine (one scan per call: ~5 000 queries are

@@ -391,8 +391,12 @@ def test_candidate_counter_mode_counts_and_keeps_results(gpu):
     assert np.array_equal(p0, p1) and np.array_equal(s0, s1)
     n_query = 2 * (len(inp["corner"]) + len(inp["surf"]))                # two outer iterations
     assert t.launches_assoc == 2
-    assert 5 * n_query * 0.5 < t.knn_candidates < 2000 * n_query       # at least ~5 per accepted query, far below the map size
-    assert h.get_timing(reset=False).knn_candidates == 0                 # reset
+    n_cand = t.knn_candidates + t.knn_candidates_seeded               # first pass (from the gate) + second pass (seeded bound)
+    assert 5 * n_query * 0.5 < n_cand < 2000 * n_query                # at least ~5 per accepted query, far below the map size
+    assert 0 < t.knn_candidates_seeded < t.knn_candidates             # the seeded pass looks at fewer candidates
+    assert t.launches_assoc_seeded == 1 and 0 < t.ms_assoc_seeded < t.ms_assoc
+    t0 = h.get_timing(reset=False)
+    assert t0.knn_candidates == 0 and t0.knn_candidates_seeded == 0      # reset
 
 
 def test_both_forms_of_the_5nn_search_agree_bit_for_bit(oracle, monkeypatch):
@@ -433,3 +437,79 @@ def test_both_forms_of_the_5nn_search_agree_bit_for_bit(oracle, monkeypatch):
     finally:
         for h in hs.values():
             h.close()
+
+
+@pytest.mark.parametrize("form", ["lane", "split"])
+def test_seeded_second_pass_finds_the_same_neighbours(oracle, monkeypatch, form):
+    """The second outer iteration's 5-NN search starts from the bound the first iteration's five neighbours give
+    (knn5_seed_bound) instead of the acceptance gate.  It must remain the EXACT top-5 by (distance, index): against a handle
+    with MSFL_KNN_SEED=0 the poses, statuses, accepted counts, iteration counts and costs are equal bit for bit -- on
+    thinned maps with holes and guesses up to a metre off (neighbour sets that change between the passes, features accepted
+    in one pass only), on the lattice map (ties at the bound, duplicates), and through both one-lane-per-query kernels
+    (`lane`: the mixed kernel of small batches; `split`: the per-kind kernel of batches of >= 65 536 features)."""
+    from msf_loam_amd import capi
+    monkeypatch.setenv("MSFL_KNN_FORM", "lane")
+    monkeypatch.setenv("MSFL_KNN_SEED", "0")
+    h0 = capi.Handle(0)
+    monkeypatch.setenv("MSFL_KNN_SEED", "1")
+    h1 = capi.Handle(0)
+    try:
+        _, mc, ms = common.small_world()
+        n_seeds = max(int(os.environ.get("MSFL_FUZZ_SEEDS", "6")), 6)
+        reps = 16 if form == "split" else 1          # 16 x ~5 000 features per job: beyond the split kernel's 65 536-feature threshold
+        for seed in range(n_seeds):
+            rng = np.random.default_rng(9100 + seed)
+            keep_c = rng.uniform(size=len(mc)) < rng.uniform(0.3, 1.0)
+            keep_s = rng.uniform(size=len(ms)) < rng.uniform(0.15, 1.0)
+            lo = rng.uniform(-15, 5, 3); hi = lo + rng.uniform(2, 12, 3)
+            keep_s &= ~np.all((ms[:, :3] > lo) & (ms[:, :3] < hi), axis=1)
+            mc2, ms2 = np.ascontiguousarray(mc[keep_c]), np.ascontiguousarray(ms[keep_s])
+            cs, ss, co, so, gs = [], [], [0], [0], []
+            for r in range(reps):
+                for pts, ring, truth, guess in common.scans(4):
+                    _, corner, surf = common.features_from_oracle(oracle, pts, ring)
+                    g = np.array(truth, np.float64)
+                    g[:3] += rng.normal(0, rng.choice([0.05, 0.3, 0.6]), 3)
+                    g[3:] = synth.quat_mul(g[3:], np.r_[0.5 * rng.normal(0, rng.choice([0.005, 0.03]), 3), 1.0]); g[3:] /= np.linalg.norm(g[3:])
+                    cs.append(corner); ss.append(surf); co.append(co[-1] + len(corner)); so.append(so[-1] + len(surf)); gs.append(g)
+            args = (np.concatenate(cs), np.array(co, np.int32), np.concatenate(ss), np.array(so, np.int32))
+            if form == "split":
+                assert co[-1] + so[-1] >= 65536
+            out = []
+            for h in (h0, h1):
+                h.set_map(mc2, ms2)
+                out.append(h.match_scan2map_batch(*args, np.array(gs)))
+            (p0, s0, i0), (p1, s1, i1) = out
+            assert np.array_equal(p0, p1) and np.array_equal(s0, s1)
+            for a, b in zip(i0, i1):
+                assert list(a.n_edge) == list(b.n_edge) and list(a.n_plane) == list(b.n_plane) and list(a.lm_iterations) == list(b.lm_iterations)
+                assert list(a.final_cost) == list(b.final_cost)
+            if seed == 0:                              # the second pass really runs seeded, on fewer candidates
+                h1.set_timing(3); h1.get_timing(reset=True)
+                h1.match_scan2map_batch(*args, np.array(gs))
+                t = h1.get_timing(reset=True); h1.set_timing(0)
+                assert 0 < t.knn_candidates_seeded < 0.8 * t.knn_candidates
+        if form == "lane":
+            # lattice map: exactly equal f32 distances at the bound, duplicated points; two different small motions between the passes
+            g_ = np.arange(-6, 7, dtype=np.float32) * 0.5
+            X, Y = np.meshgrid(g_, g_, indexing="ij")
+            plane = np.stack([X.ravel(), Y.ravel(), np.full(X.size, -1.5, np.float32)], 1)
+            wall = np.stack([np.full(X.size, 3.5, np.float32), X.ravel(), Y.ravel() + 1.5], 1)
+            lat = np.concatenate([plane, wall, plane[::7]])
+            lat = np.concatenate([lat, np.zeros((len(lat), 1), np.float32)], 1).astype(np.float32)
+            line = np.stack([np.zeros(60, np.float32), np.zeros(60, np.float32), np.arange(60, dtype=np.float32) * 0.125], 1)
+            pole = np.concatenate([line, line[::5]]); pole = np.concatenate([pole, np.zeros((len(pole), 1), np.float32)], 1).astype(np.float32)
+            rng = np.random.default_rng(4)
+            q = np.concatenate([plane[rng.integers(0, len(plane), 300)] + rng.choice([0.0, 0.25, 0.125], (300, 3)).astype(np.float32),
+                                wall[rng.integers(0, len(wall), 300)] + rng.choice([0.0, 0.25, -0.125], (300, 3)).astype(np.float32)])
+            surf = np.concatenate([q, np.zeros((len(q), 1), np.float32)], 1).astype(np.float32)
+            corner = np.concatenate([line[::3] + np.float32(0.05), np.zeros((20, 1), np.float32)], 1).astype(np.float32)
+            for pose in (np.array([0, 0, 0, 0, 0, 0, 1.0]), np.array([0.125, -0.25, 0.0, 0, 0, 0, 1.0]), np.array([0.01, 0.02, -0.03, 0, 0, 0.002, 1.0])):
+                res = []
+                for h in (h0, h1):
+                    h.set_map(pole, lat)
+                    res.append(h.match_scan2map(corner, surf, pose / np.r_[1, 1, 1, [np.linalg.norm(pose[3:])] * 4]))
+                assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+                assert list(res[0][2].n_plane) == list(res[1][2].n_plane) and list(res[0][2].final_cost) == list(res[1][2].final_cost)
+    finally:
+        h0.close(); h1.close()

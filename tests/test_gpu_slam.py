@@ -141,3 +141,26 @@ def test_launch_bounds_do_not_change_the_result():
         assert (a.n_corner_ds, a.n_surf_ds, a.n_map_corner, a.n_map_surf) == (b.n_corner_ds, b.n_surf_ds, b.n_map_corner, b.n_map_surf)
         assert list(a.grid_corner)[:3] == list(b.grid_corner)[:3] and list(a.grid_surf)[:3] == list(b.grid_surf)[:3]
     tight.close(); loose.close()
+
+
+def test_mapping_thread_gives_the_same_poses(monkeypatch):
+    """MSFL_SLAM_THREADS=1: the mapping chain of every scan is enqueued by a second host thread (the reference's own layout,
+    laser_mapping.cc:86).  The GPU-side order is fixed by events, so poses, counts and map stores equal the single-thread
+    form bit for bit, pipelined and synchronous."""
+    import os
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import replay_synthetic as rp
+    world = synth.World(ground_half=45.0)
+    truth = rp.trajectory(120)[:40]
+    scans = [synth.make_scan(world, truth[k], synth.SEED + 5000 + k) for k in range(len(truth))]
+    monkeypatch.setenv("MSFL_SLAM_THREADS", "0")
+    ref, recs0, _ = rp.run_slam(world, truth, pipelined=True, scans=scans)
+    monkeypatch.setenv("MSFL_SLAM_THREADS", "1")
+    for pipelined in (True, False):
+        maps = {}
+        est, recs, _ = rp.run_slam(world, truth, pipelined=pipelined, scans=scans, maps_out=maps)
+        assert np.array_equal(est, ref)
+        assert [list(r.grid_surf)[:2] for r in recs] == [list(r.grid_surf)[:2] for r in recs0]
