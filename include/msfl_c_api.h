@@ -124,10 +124,11 @@ typedef struct msfl_timing {
   int    launches_extract; double ms_extract;   /* feature extraction (all kernels)   */
   int    launches_odom;    double ms_odom;      /* scan-to-scan association kernel    */
   int    launches_fit;     double ms_fit;       /* line / plane fit kernel            */
-  unsigned long long knn_candidates;            /* map points whose distance the 5-NN kernel evaluated (mode 3 only): launches that start
-                                                   from the acceptance gate (the first outer iteration) */
-  unsigned long long knn_candidates_seeded;     /* the same for launches that start from the previous iteration's neighbours (the second) */
-  int    launches_assoc_seeded; double ms_assoc_seeded;   /* the seeded 5-NN launches alone (they are also part of launches_assoc / ms_assoc) */
+  unsigned long long knn_candidates;            /* map points whose distance the 5-NN kernel evaluated (mode 3 only): the launches of the
+                                                   first outer iteration */
+  unsigned long long knn_candidates_seeded;     /* the same for the launches of the second outer iteration (which start from the bound the first
+                                                   iteration's neighbours give when MSFL_KNN_SEED=1, from the acceptance gate otherwise) */
+  int    launches_assoc_seeded; double ms_assoc_seeded;   /* the second iteration's 5-NN launches alone (also part of launches_assoc / ms_assoc) */
 } msfl_timing;
 
 /* ------------------------------------------------------------------------------------------ */

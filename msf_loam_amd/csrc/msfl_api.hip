@@ -136,7 +136,8 @@ struct msfl_handle_s {
   bool voxel_force_global = false;        // MSFL_VOXEL_GLOBAL=1: the batched voxel filter keeps the device-wide radix-sort form (A/B testing)
   long long odom_wave_max_targets = -1;   // MSFL_ODOM_WAVE_MAX_TARGETS: previous-scan points up to which a small batch takes the one-wavefront-per-query kernel (default 4096 per pair)
   bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)
-  bool knn_seed = true;                   // MSFL_KNN_SEED=0: the second outer iteration's 5-NN search starts from the gate like the first (A/B)
+  bool knn_seed = false;                  // MSFL_KNN_SEED=1: the second outer iteration's 5-NN search starts from the bound the first one's neighbours give
+                                          // (exact; measured slower, docs/rejected_experiments.md: -16 % candidates, +13 % launch time)
   int knn_form = 0;                       // MSFL_KNN_FORM: 0 auto (row-parallel latency form for launches of <= kKnnRowsMaxRecords queries),
                                           // 1 "lane" (one lane per query always), 2 "rows" (row-parallel always); results are identical
 
@@ -307,8 +308,8 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi, 
 // seed: `nn` still holds this batch's neighbours from the previous outer iteration (same records, same map index): the 5-NN search
 // starts from the bound they give (knn5_seed_bound; exact, MSFL_KNN_SEED=0 switches it off for A/B)
 void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_poses, const int* d_status, bool deskew,
-                    const DeskewView& dv, int n_rec, double* full = nullptr, int rec_begin = 0, int rec_end = -1, bool seed = false) {
-  seed = seed && h->knn_seed;
+                    const DeskewView& dv, int n_rec, double* full = nullptr, int rec_begin = 0, int rec_end = -1, bool second_pass = false) {
+  const bool seed = second_pass && h->knn_seed;
   hipStream_t st = h->stream;
   int* nn = h->nn.as<int>();
   BatchView bv = bv_all;
@@ -316,7 +317,7 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
   if (n_rec <= 0) return;
   const dim3 grid(div_up(n_rec, kAssocBlock)), block(kAssocBlock);
   {
-    ScopedTimer timer(h, seed ? T_ASSOC_SEEDED : T_ASSOC);
+    ScopedTimer timer(h, second_pass ? T_ASSOC_SEEDED : T_ASSOC);      // second-pass launches are timed (and counted) on their own, seeded or not
     if (h->timing == 3) {
       unsigned long long* cnt = h->knn_count.as<unsigned long long>();
       if (deskew)
@@ -336,7 +337,7 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
                            (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
                            (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
                            (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
-                           h->prm.map_knn_max_sq_dist, dv, nn, cnt);
+                           h->prm.map_knn_max_sq_dist, dv, nn, cnt + (second_pass ? 1 : 0));
     } else if (!deskew && !bv.dyn && rec_end < 0 && n_rec >= 65536) {       // a whole large batch: one body per feature kind (-2 %)
       const int n_s = bv.n_surf_total, n_c = n_rec - n_s;
       const int edge_blocks = div_up(n_c, kAssocBlock), plane_blocks = div_up(n_s, kAssocBlock);
