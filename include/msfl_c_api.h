@@ -208,6 +208,25 @@ msfl_status msfl_match_scan2map_batch(msfl_handle* h, int n_scans,
                                       double* poses_io, int* status, msfl_match_info* info,
                                       msfl_mem mem);
 
+/* P independent (map, scan) PAIRS in one call: scan p is registered against map p only ("many map-submap pairs").  The
+   reference analogue is one MatchScan2Map call per pair, each rebuilding both kd-trees (mapping_scan_matcher.cc:66-73;
+   laser_mapping.cc:304-311).  Here the P maps are indexed together (one exact-kNN grid per pair inside one set of arrays,
+   four launches + one scan per cloud kind whatever P is) and the P registrations run as one batch.
+     map_corner, map_corner_off : the P corner map clouds concatenated + P+1 prefix offsets (HOST array, like every batch
+                                  call); same for map_surf.
+     corner / surf + offsets    : the P scans' (down-sampled) feature clouds, as in msfl_match_scan2map_batch.
+     poses_io, status, info     : as there.  status[p] = MSFL_MAP_TOO_SMALL for a pair whose corner or surf map has fewer
+                                  than 5 points (the pose guess passes through); the call itself still returns MSFL_OK.
+   Results equal P calls of msfl_set_map + msfl_match_scan2map bit for bit.  With MSFL_MEM_DEVICE the clouds, poses_io and
+   status are device pointers and the call is asynchronous.  The handle's resident single map (msfl_set_map) is replaced:
+   call msfl_set_map again before the next msfl_match_scan2map*. */
+msfl_status msfl_match_pairs_batch(msfl_handle* h, int n_pairs,
+                                   const msfl_point* map_corner, const int* map_corner_off,
+                                   const msfl_point* map_surf, const int* map_surf_off,
+                                   const msfl_point* corner, const int* corner_off,
+                                   const msfl_point* surf, const int* surf_off,
+                                   double* poses_io, int* status, msfl_match_info* info, msfl_mem mem);
+
 /* Kernel-level entry points (the two halves of one outer iteration), exposed so that parity tests
    can pin the data association and the solver separately:
      msfl_associate_scan2map : mapping_scan_matcher.cc:109-246 at a fixed pose.  records_out gets
@@ -360,8 +379,12 @@ msfl_status msfl_extract_features_batch(msfl_handle* h, int n_scans,
 
 /* Centroid voxel filter with PCL VoxelGrid semantics (leaf cube, centroid of x,y,z,t per
    occupied voxel, output ordered by voxel index).  out has capacity n; *n_out receives the
-   count.  A non-finite point is refused with MSFL_BAD_ARG (pcl::VoxelGrid would drop it; the
-   reference's clouds never hold one, msf_loam_node.cc:85-111), also in the batch form. */
+   count.  Non-finite points are DROPPED, as pcl::VoxelGrid::applyFilter does for a cloud that is
+   not dense (`if (!input_->is_dense) if (!pcl_isfinite(...)) continue;`): a stable device-side
+   compaction followed by the same filter.  (For a cloud flagged dense PCL does not look and its
+   result is undefined; the reference's clouds never hold such a point, msf_loam_node.cc:85-111.)
+   The batch forms below REFUSE a cloud with a non-finite point (MSFL_BAD_ARG): their inputs are
+   the extraction's own outputs. */
 msfl_status msfl_voxel_downsample(msfl_handle* h,
                                   const msfl_point* pts, int n, float leaf,
                                   msfl_point* out, int* n_out, msfl_mem mem);

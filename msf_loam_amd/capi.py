@@ -18,7 +18,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 EXPORTED = [
     "msfl_default_params", "msfl_api_version", "msfl_create", "msfl_destroy", "msfl_set_stream", "msfl_reset_stream",
     "msfl_synchronize", "msfl_status_string", "msfl_last_error", "msfl_set_timing", "msfl_get_timing",
-    "msfl_set_map", "msfl_match_scan2map", "msfl_match_scan2map_batch", "msfl_match_scan2map_deskew",
+    "msfl_set_map", "msfl_match_scan2map", "msfl_match_scan2map_batch", "msfl_match_pairs_batch", "msfl_match_scan2map_deskew",
     "msfl_match_scan2map_deskew_batch",
     "msfl_associate_scan2map", "msfl_solve_records",
     "msfl_match_scan2scan", "msfl_match_scan2scan_batch", "msfl_extract_features",
@@ -427,6 +427,27 @@ class Handle:
                                                          _vp(cnt_a) if cnt_a is not None else None, C.c_float(leaf), _vp(out), _vp(out_off),
                                                          C.c_int(MEM_HOST)), "msfl_voxel_downsample_batch")
         return out[:out_off[-1]].copy(), out_off
+
+    def match_pairs_batch(self, map_corner, map_corner_off, map_surf, map_surf_off, corner, corner_off, surf, surf_off, poses, want_info=False):
+        """P (map, scan) pairs with distinct maps in one call (host memory) -> (poses (P,7), status (P,), info list or None)."""
+        mc, ms, c, s_ = _pts(map_corner), _pts(map_surf), _pts(corner), _pts(surf)
+        offs = [np.ascontiguousarray(o, np.int32) for o in (map_corner_off, map_surf_off, corner_off, surf_off)]
+        P = len(offs[0]) - 1
+        poses = np.ascontiguousarray(np.array(poses, np.float64).reshape(P, 7))
+        status = np.zeros(P, np.int32)
+        info = (MatchInfo * P)() if want_info else None
+        self._check(self.lib.msfl_match_pairs_batch(self.h, C.c_int(P), _vp(mc), _vp(offs[0]), _vp(ms), _vp(offs[1]), _vp(c), _vp(offs[2]),
+                                                    _vp(s_), _vp(offs[3]), _vp(poses), _vp(status), info, C.c_int(MEM_HOST)), "msfl_match_pairs_batch")
+        return poses, status, info
+
+    def match_pairs_batch_device(self, P, d_map_corner, map_corner_off, d_map_surf, map_surf_off, d_corner, corner_off, d_surf, surf_off,
+                                 d_poses, d_status):
+        """The same with device-resident clouds / poses / status (torch tensors or raw pointers) and host offset arrays; asynchronous."""
+        offs = [np.ascontiguousarray(o, np.int32) for o in (map_corner_off, map_surf_off, corner_off, surf_off)]
+        self._keep_offs = offs
+        self._check(self.lib.msfl_match_pairs_batch(self.h, C.c_int(P), _vp(d_map_corner), _vp(offs[0]), _vp(d_map_surf), _vp(offs[1]), _vp(d_corner),
+                                                    _vp(offs[2]), _vp(d_surf), _vp(offs[3]), _vp(d_poses), _vp(d_status), None, C.c_int(MEM_DEVICE)),
+                    "msfl_match_pairs_batch(device)")
 
     def transform_cloud(self, pts, pose7):
         """TransformPointCloud (laser_mapping.cc:24-31)."""

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -152,6 +153,7 @@ struct msfl_handle_s {
   DevBuf vb[14];  // batched voxel filter
   DevBuf vb2[6];  // second scratch set of the pair form: staging, run sums, counts/flags/offsets, offsets
   DevBuf pp[5];   // per-point passes: pre-integration samples, staged points, dq, dp, flag
+  DevBuf pr[5];   // batched (map, scan) pairs: map offsets and cell-table bases per cloud kind, preset status
 
   PinRing pin;
   PinBuf readback;
@@ -577,6 +579,7 @@ void msfl_destroy(msfl_handle* h) {
   for (auto& b : h->ex) b.release();
   for (auto& b : h->od) b.release();
   for (auto& b : h->pp) b.release();
+  for (auto& b : h->pr) b.release();
   for (auto& b : h->vb) b.release();
   for (auto& b : h->vb2) b.release();
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -915,3 +918,4 @@ msfl_status msfl_solve_records(msfl_handle* h, const msfl_point* corner, int n_c
 #include "msfl_api_grid.inc"
 #include "msfl_api_deskew.inc"
 #include "msfl_api_slam.inc"
+#include "msfl_api_pairs.inc"

@@ -508,13 +508,15 @@ struct DeskewView {
 #define MSFL_ASSOC_BLOCK 64
 #endif
 constexpr int kAssocBlock = MSFL_ASSOC_BLOCK;      // threads per workgroup of the 5-NN and fit kernels
-template <bool DESKEW, bool COUNT = false, bool SEED = false>
+// PAIRS: scan b is registered against ITS OWN map (msfl_pairs.cuh): descriptor gcp[b] / gsp[b], cell table slice at cbase_*[b]
+template <bool DESKEW, bool COUNT = false, bool SEED = false, bool PAIRS = false>
 __global__ void __launch_bounds__(kAssocBlock)
 knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* __restrict__ status,
                      const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
                      const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
                      const int* __restrict__ pos_c, const int* __restrict__ pos_s,
-                     float max_sq_dist, DeskewView dv, int* __restrict__ nn, unsigned long long* __restrict__ n_candidates = nullptr) {
+                     float max_sq_dist, DeskewView dv, int* __restrict__ nn, unsigned long long* __restrict__ n_candidates = nullptr,
+                     const int* __restrict__ cbase_c = nullptr, const int* __restrict__ cbase_s = nullptr) {
   const int g = bv.rec_begin + blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= batch_records(bv)) return;
   const int b = find_scan_wave(bv.rec_off, bv.n_scans, g);
@@ -551,8 +553,8 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   Top5 t;
   int n_cand = 0;
   const float bound = SEED ? knn5_seed_bound(is_edge ? map_c : map_s, out, q, max_sq_dist) : max_sq_dist;
-  if (is_edge) { const GridDesc gc = *gcp; knn5_grid(gc, map_c, cs_c, q, bound, t, n_cand); }
-  else { const GridDesc gs = *gsp; knn5_grid(gs, map_s, cs_s, q, bound, t, n_cand); }
+  if (is_edge) { const GridDesc gc = gcp[PAIRS ? b : 0]; knn5_grid(gc, map_c, cs_c + (PAIRS ? cbase_c[b] : 0), q, bound, t, n_cand); }
+  else { const GridDesc gs = gsp[PAIRS ? b : 0]; knn5_grid(gs, map_s, cs_s + (PAIRS ? cbase_s[b] : 0), q, bound, t, n_cand); }
   if (COUNT) {                                                  // one atomic per wavefront: sum over the lanes still here
     const unsigned long long act = __ballot(1);
     unsigned long long m = act;

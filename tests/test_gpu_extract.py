@@ -248,24 +248,32 @@ def test_randomised_odd_scans_bit_exact(gpu, oracle, seed):
     _check(f, fo)
 
 
-def test_voxel_filters_refuse_non_finite_points(gpu):
-    """ADVICE r01: a NaN / Inf point must not be averaged into a centroid (pcl::VoxelGrid drops it on non-dense
-    clouds).  The reference never produces one (RemoveInvalidPointsFromCloud); the public filters refuse the call."""
+def test_voxel_filter_drops_non_finite_points_like_pcl(gpu, oracle):
+    """pcl::VoxelGrid::applyFilter skips non-finite points of a non-dense cloud (`if (!input_->is_dense) if (!pcl_isfinite ...)
+    continue;`): msfl_voxel_downsample does the same (device-side compaction, then the filter), so the result equals the filter
+    of the finite points alone, bit for bit, whatever NaN / Inf coordinates are sprinkled in.  A cloud of nothing but such
+    points gives an empty result.  The batch forms (fed by the extraction, which cannot emit one) refuse the cloud."""
     from msf_loam_amd import capi
     rng = np.random.default_rng(1)
-    pts = np.zeros((500, 4), np.float32)
-    pts[:, :3] = rng.uniform(-5, 5, (500, 3))
-    assert len(gpu.voxel_downsample(pts, 0.4)) > 0
+    pts = np.zeros((5000, 4), np.float32)
+    pts[:, :3] = rng.uniform(-5, 5, (5000, 3)); pts[:, 3] = rng.uniform(0, 0.1, 5000)
+    clean = gpu.voxel_downsample(pts, 0.4)
+    assert len(clean) > 0 and np.array_equal(clean, oracle.voxel_grid(pts, 0.4))
     for bad in (np.nan, np.inf, -np.inf):
-        q = pts.copy(); q[123, 1] = bad
+        q = pts.copy()
+        hit = rng.choice(len(q), 37, replace=False)
+        q[hit, rng.integers(0, 3, 37)] = bad
+        keep = np.ones(len(q), bool); keep[hit] = False
+        out = gpu.voxel_downsample(q, 0.4)
+        assert np.array_equal(out, oracle.voxel_grid(q[keep], 0.4))          # = PCL on the finite points, arrival order kept
         with pytest.raises(capi.MsflError) as e:
-            gpu.voxel_downsample(q, 0.4)
+            gpu.voxel_downsample_batch(np.concatenate([pts, q]), np.array([0, 5000, 10000], np.int32), 0.4)
         assert e.value.status == capi.BAD_ARG
-        with pytest.raises(capi.MsflError) as e:
-            gpu.voxel_downsample_batch(np.concatenate([pts, q]), np.array([0, 500, 1000], np.int32), 0.4)
-        assert e.value.status == capi.BAD_ARG
-    out, off = gpu.voxel_downsample_batch(np.concatenate([pts, pts]), np.array([0, 500, 1000], np.int32), 0.4)
-    assert off[1] == off[2] - off[1] == len(gpu.voxel_downsample(pts, 0.4))
+    allbad = pts.copy(); allbad[:, 0] = np.nan
+    assert len(gpu.voxel_downsample(allbad, 0.4)) == 0
+    assert np.array_equal(gpu.voxel_downsample(pts, 0.4), clean)                # and the handle is fine afterwards
+    out, off = gpu.voxel_downsample_batch(np.concatenate([pts, pts]), np.array([0, 5000, 10000], np.int32), 0.4)
+    assert off[1] == off[2] - off[1] == len(clean)
 
 
 def test_batched_voxel_filter_lds_form_and_its_fallbacks(oracle, monkeypatch):
