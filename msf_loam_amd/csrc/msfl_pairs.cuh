@@ -10,7 +10,7 @@
 //                host-known bounds, 2 x points + 4 096; the device grows a pair's cell edge until its grid fits its slice),
 //                unused cells count zero, so ONE exclusive scan over the whole array yields every pair's cell starts
 //   descriptors  GridDesc[P]
-// Four launches + one rocPRIM scan per cloud kind, whatever P is.
+// Five launches + one rocPRIM scan per cloud kind, whatever P is.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -18,21 +18,33 @@
 
 namespace msfl {
 
-// one workgroup per pair: bounding box of its cloud -> its GridDesc (cell edge grown until the grid fits cap[p] cells)
+// per-pair bounding boxes as six order-preserving ints (the encoding of grid_bbox_kernel): armed, then one thread per map point
+// of the concatenated clouds; a workgroup that lies inside one pair (nearly all do) reduces first and issues six atomics
+__global__ void __launch_bounds__(256) pairs_arm_kernel(int* __restrict__ bbox, int n_pairs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 6 * n_pairs) bbox[i] = (i % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+}
+
 __global__ void __launch_bounds__(256)
-pairs_desc_kernel(const float4* __restrict__ pts, const int* __restrict__ off, const int* __restrict__ cell_base, double radius,
-                  GridDesc* __restrict__ gdesc) {
+pairs_bbox_kernel(const float4* __restrict__ pts, int n, const int* __restrict__ off, int n_pairs, int* __restrict__ bbox) {
   __shared__ float s_mn[4][3], s_mx[4][3];
-  __shared__ int s_bbox[6];
-  const int p = blockIdx.x;
-  const int lo = off[p], hi = off[p + 1];
+  __shared__ int s_pair[2];
+  const int i = off[0] + blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = i < off[0] + n;
+  const int p = in ? find_scan_wave(off, n_pairs, i) : -1;
+  if (threadIdx.x == 0) s_pair[0] = p;
+  const int last = min((int)(blockIdx.x * blockDim.x) + 255, n - 1);
+  if ((int)(blockIdx.x * blockDim.x + threadIdx.x) == last) s_pair[1] = p;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int i = lo + (int)threadIdx.x; i < hi; i += 256) {
+  if (in) {
     const float4 q = pts[i];
-    if (isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) {
-      mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
-      mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
-    }
+    if (isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) { mn[0] = mx[0] = q.x; mn[1] = mx[1] = q.y; mn[2] = mx[2] = q.z; }
+  }
+  __syncthreads();
+  if (s_pair[0] != s_pair[1]) {                  // a workgroup across a pair boundary: every lane for itself
+    if (in && mn[0] != INFINITY)
+      for (int a = 0; a < 3; a++) { atomicMin(&bbox[6 * p + a], float_to_ordered(mn[a])); atomicMax(&bbox[6 * p + 3 + a], float_to_ordered(mx[a])); }
+    return;
   }
 #pragma unroll
   for (int a = 0; a < 3; a++) {
@@ -42,16 +54,24 @@ pairs_desc_kernel(const float4* __restrict__ pts, const int* __restrict__ off, c
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) { for (int a = 0; a < 3; a++) { s_mn[wave][a] = mn[a]; s_mx[wave][a] = mx[a]; } }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int a = 0; a < 3; a++) {
-      const float lo_a = fminf(fminf(s_mn[0][a], s_mn[1][a]), fminf(s_mn[2][a], s_mn[3][a]));
-      const float hi_a = fmaxf(fmaxf(s_mx[0][a], s_mx[1][a]), fmaxf(s_mx[2][a], s_mx[3][a]));
-      s_bbox[a] = lo_a != INFINITY ? float_to_ordered(lo_a) : 0x7fffffff;        // the encoding grid_desc_from_bbox reads
-      s_bbox[3 + a] = hi_a != -INFINITY ? float_to_ordered(hi_a) : (int)0x80000000;
-    }
-    GridDesc g = grid_desc_from_bbox(s_bbox, radius, cell_base[p + 1] - cell_base[p]);
-    gdesc[p] = g;
+  const int pp = s_pair[0];
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    const float v = fminf(fminf(s_mn[0][a], s_mn[1][a]), fminf(s_mn[2][a], s_mn[3][a]));
+    if (v != INFINITY) atomicMin(&bbox[6 * pp + a], float_to_ordered(v));
+  } else if (threadIdx.x < 6) {
+    const int a = threadIdx.x - 3;
+    const float v = fmaxf(fmaxf(s_mx[0][a], s_mx[1][a]), fmaxf(s_mx[2][a], s_mx[3][a]));
+    if (v != -INFINITY) atomicMax(&bbox[6 * pp + 3 + a], float_to_ordered(v));
   }
+}
+
+// one thread per pair: its GridDesc (cell edge grown until the grid fits the pair's slice of the cell table)
+__global__ void __launch_bounds__(256)
+pairs_desc_kernel(const int* __restrict__ bbox, int n_pairs, const int* __restrict__ cell_base, double radius, GridDesc* __restrict__ gdesc) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  gdesc[p] = grid_desc_from_bbox(bbox + 6 * p, radius, cell_base[p + 1] - cell_base[p]);
 }
 
 // one thread per map point of the concatenated clouds: its pair, its cell in that pair's grid
