@@ -374,15 +374,26 @@ class HybridGrid {
 // LaserOdometry + LaserMapping as one device-resident pipeline (msfl_slam_*): the raw cloud of
 // RealHandleLaserCloudMessage (msf_loam_node.cc:160-167) in, pose_scan2world_ (laser_odometry.cc:79) and
 // pose_map_scan2world_ (laser_mapping.cc:304-311) out; the feature clouds, the two surrounded map clouds, both HybridGrids
-// and the pose chain never leave the GPU.  LiDAR-only branch (estimator not initialised).
+// and the pose chain never leave the GPU.  AddLaserScan(cloud) is the LiDAR-only form; AddLaserScan(cloud, ImuInputs) runs the
+// IMU branches of LaserMapping::Run (UndistortScan, laser_mapping.cc:170-176, or the is_initialized matcher + DoUndistort,
+// :197-211) from what the maintainer's estimator hands over.
 class LaserSlam {
  public:
   struct Poses { Rigid3d odom, map; bool mapped; int scan_index; };
+  // the per-scan products of the code that stays on the maintainer's side (msfl_slam_imu)
+  struct ImuInputs {
+    std::shared_ptr<IntegrationBase> preintegration;       // BuildPreintegration(imu_buf_, odom_result.time), laser_mapping.cc:191-194
+    bool is_initialized = false;                            // estimator_.IsInitialized()
+    Vector3d velocity{{0, 0, 0}}, gravity{{0, 0, 0}};      // bias_j.head<3>() of the pre-solve, estimator_.GetGravityVector()
+    Rigid3d presolved_pose = Rigid3d::Identity();           // pose_j of the IMU-only pre-solve (mapping_scan_matcher.cc:35-59)
+  };
 
-  explicit LaserSlam(int device = 0, int max_scan_points = 200000, int max_rings = 128, const Rigid3d& pose_odom2map = Rigid3d::Identity()) {
+  // reference_quirks: FilterLessFlatLessCornerFeature as the reference executes it (laser_mapping.cc:340-364), see msfl_slam_config
+  explicit LaserSlam(int device = 0, int max_scan_points = 200000, int max_rings = 128, const Rigid3d& pose_odom2map = Rigid3d::Identity(),
+                     bool reference_quirks = false) {
     msfl_slam_config c;
     msfl_slam_default_config(&c);
-    c.max_scan_points = max_scan_points; c.max_rings = max_rings;
+    c.max_scan_points = max_scan_points; c.max_rings = max_rings; c.reference_quirks = reference_quirks ? 1 : 0;
     const auto v = pose_odom2map.ToVector7();
     for (int k = 0; k < 7; ++k) c.pose_odom2map[k] = v[k];
     const msfl_status st = msfl_slam_create(nullptr, &c, device, &s_);
@@ -395,12 +406,17 @@ class LaserSlam {
   // LaserOdometry::AddLaserScan + one LaserMapping::Run iteration; waits for this scan's mapping result.
   // `mapped` is false when the map gate (laser_mapping.cc:284-285) kept MatchScan2Map from running.
   Poses AddLaserScan(const PointCloud<PointTypeOriginal>& laser_cloud_in) {
-    Enqueue(laser_cloud_in, &rec_);
+    Enqueue(laser_cloud_in, nullptr, &rec_);
+    return Unpack(rec_);
+  }
+  Poses AddLaserScan(const PointCloud<PointTypeOriginal>& laser_cloud_in, const ImuInputs& imu) {
+    Enqueue(laser_cloud_in, &imu, &rec_);
     return Unpack(rec_);
   }
   // The two-thread form: enqueue scan k (returns its index at once), fetch results one scan late with Result(k - 1); the
   // odometry chain of scan k then runs under the mapping chain of scan k - 1.
-  int AddLaserScanAsync(const PointCloud<PointTypeOriginal>& laser_cloud_in) { Enqueue(laser_cloud_in, nullptr); return n_ - 1; }
+  int AddLaserScanAsync(const PointCloud<PointTypeOriginal>& laser_cloud_in) { Enqueue(laser_cloud_in, nullptr, nullptr); return n_ - 1; }
+  int AddLaserScanAsync(const PointCloud<PointTypeOriginal>& laser_cloud_in, const ImuInputs& imu) { Enqueue(laser_cloud_in, &imu, nullptr); return n_ - 1; }
   Poses Result(int scan_index) {
     const msfl_status st = msfl_slam_get_result(s_, scan_index, &rec_);
     if (st != MSFL_OK) throw std::runtime_error(std::string("msfl_slam_get_result: ") + msfl_status_string(st) + " " + msfl_slam_last_error(s_));
@@ -409,16 +425,36 @@ class LaserSlam {
   const msfl_slam_result& last_record() const { return rec_; }
 
  private:
-  void Enqueue(const PointCloud<PointTypeOriginal>& in, msfl_slam_result* out) {
+  void Enqueue(const PointCloud<PointTypeOriginal>& in, const ImuInputs* imu, msfl_slam_result* out) {
     std::vector<msfl_point> p; std::vector<std::uint16_t> r;
     detail::Pack(in, &p, &r);
-    const msfl_status st = msfl_slam_add_scan(s_, p.data(), r.data(), static_cast<int>(p.size()), MSFL_MEM_HOST, out);
+    msfl_slam_imu mi{};
+    msfl_preintegration pre{};
+    std::vector<double> dq, dp;
+    if (imu && imu->preintegration) {
+      const IntegrationBase& ib = *imu->preintegration;
+      const std::size_t n = ib.sum_dt_buf_.size();
+      if (ib.delta_q_buf_.size() != n || ib.delta_p_buf_.size() != n) throw std::invalid_argument("LaserSlam: pre-integration buffers of different length");
+      dq.resize(4 * n); dp.resize(3 * n);
+      for (std::size_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 4; ++k) dq[4 * i + k] = ib.delta_q_buf_[i][k];
+        for (int k = 0; k < 3; ++k) dp[3 * i + k] = ib.delta_p_buf_[i][k];
+      }
+      pre.sum_dt = ib.sum_dt_buf_.data(); pre.delta_q = dq.data(); pre.delta_p = dp.data(); pre.n = static_cast<int>(n);
+      mi.pre = &pre; mi.is_initialized = imu->is_initialized ? 1 : 0;
+      const auto v = imu->presolved_pose.ToVector7();
+      for (int k = 0; k < 7; ++k) mi.presolved_pose[k] = v[k];
+      for (int k = 0; k < 3; ++k) { mi.velocity[k] = imu->velocity[k]; mi.gravity[k] = imu->gravity[k]; }
+    }
+    const msfl_status st = msfl_slam_add_scan_imu(s_, p.data(), r.data(), static_cast<int>(p.size()), MSFL_MEM_HOST, imu ? &mi : nullptr, out);
     if (st != MSFL_OK) throw std::runtime_error(std::string("msfl_slam_add_scan: ") + msfl_status_string(st) + " " + msfl_slam_last_error(s_));
     ++n_;
   }
   static Poses Unpack(const msfl_slam_result& r) {
     if (r.status_extract != MSFL_OK)          // the reference CHECK-aborts on these (msf_loam_node.cc:136,186,200)
       throw std::runtime_error(std::string("feature extraction: ") + msfl_status_string(r.status_extract));
+    if (r.status_imu != MSFL_OK)              // GetDeltaQP's CHECK (scan_undistortion.cc:26-30)
+      throw std::runtime_error("a point's relative time lies outside the pre-integration span");
     std::array<double, 7> o, m;
     for (int k = 0; k < 7; ++k) { o[k] = r.pose_odom[k]; m[k] = r.pose_map[k]; }
     return Poses{Rigid3d(o), Rigid3d(m), r.status_mapping == MSFL_OK, r.scan_index};

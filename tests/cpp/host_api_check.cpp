@@ -83,7 +83,23 @@ int main(int argc, char** argv) {
   const int k2 = slam.AddLaserScanAsync(cloud);
   const auto s1 = slam.Result(k1);
   const auto s2 = slam.Result(k2);
-  const bool slam_ok = !s0.mapped && s1.mapped && s2.mapped && s0.scan_index == 0 && s1.scan_index == 1 && s2.scan_index == 2;
+  bool slam_ok = !s0.mapped && s1.mapped && s2.mapped && s0.scan_index == 0 && s1.scan_index == 1 && s2.scan_index == 2;
+  {
+    // LaserMapping::Run with IMU inputs and the reference's surf-list truncation: UndistortScan on the first two scans, the
+    // is_initialized branch (pre-solved pose, Deskew factors, DoUndistort before the insert) on the third
+    msfl::LaserSlam slam2(0, n, 16, msfl::Rigid3d(std::array<double, 7>{{guess[0], guess[1], guess[2], guess[3], guess[4], guess[5], guess[6]}}), true);
+    msfl::LaserSlam::ImuInputs imu;
+    imu.preintegration = pre;
+    const auto q0 = slam2.AddLaserScan(cloud, imu);
+    const auto q1 = slam2.AddLaserScan(cloud, imu);
+    imu.is_initialized = true;
+    imu.velocity = msfl::Vector3d{{vel_in[0], vel_in[1], vel_in[2]}};
+    imu.gravity = gravity;
+    imu.presolved_pose = q1.map;
+    const auto q2 = slam2.AddLaserScan(cloud, imu);
+    const msfl_slam_result& rr = slam2.last_record();
+    slam_ok = slam_ok && !q0.mapped && q1.mapped && q2.mapped && rr.status_imu == 0 && rr.n_surf_ds > 0 && rr.n_surf_ds <= rr.n_less_sharp;
+  }
   FILE* o = fopen(argv[2], "wb");
   auto v = pose.ToVector7(); auto w = rel.ToVector7();
   fwrite(v.data(), 8, 7, o); fwrite(w.data(), 8, 7, o);
