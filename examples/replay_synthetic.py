@@ -227,6 +227,7 @@ def main():
     ap.add_argument("--mode", choices=["slam", "slam-pipelined", "staged"], default="slam",
                     help="slam: msfl_slam_add_scan, one synchronisation per scan; slam-pipelined: results fetched one scan late; "
                          "staged: the round-2 loop of single-stage host-pointer calls")
+    ap.add_argument("--dump-poses", default=None, help="write the estimated map poses (n x 7 float64, .npy) here")
     ap.add_argument("--reference-quirks", action="store_true", help="msfl_slam_config.reference_quirks = 1 (surf list truncation of the reference)")
     ap.add_argument("--imu", action="store_true", help="feed a synthetic pre-integration with every scan (UndistortScan, then the is_initialized branch from scan 50)")
     args = ap.parse_args()
@@ -244,12 +245,16 @@ def main():
     est, recs, ms = run_slam(world, truth, pipelined=args.mode == "slam-pipelined", scans=scans, quirks=args.reference_quirks,
                              imu=synthetic_imu(truth) if args.imu else None)
     last = recs[-1]
+    if args.dump_poses:
+        np.save(args.dump_poses, est)
     print(json.dumps({"mode": args.mode, "scans": args.scans, "reference_quirks": bool(args.reference_quirks), "imu": bool(args.imu),
                       "ate_rmse_m": ate(est, truth),
                       "final_error_m_rad": synth.pose_error(est[-1], truth[-1]), "ms_per_scan_end_to_end": ms,
                       "scans_per_s": 1e3 / ms if ms else None,
                       "map_points": [last.grid_corner[0], last.grid_surf[0]], "map_cells": [last.grid_corner[1], last.grid_surf[1]],
                       "mapping_gate_closed_scans": int(sum(1 for r in recs if r.status_mapping != 0)),
+                      "mean_features_after_voxel": [float(np.mean([r.n_corner_ds for r in recs])), float(np.mean([r.n_surf_ds for r in recs]))],
+                      "mean_surrounded_map_points": [float(np.mean([r.n_map_corner for r in recs])), float(np.mean([r.n_map_surf for r in recs]))],
                       "note": "raw host scan in (18 B/pt over PCIe), 480-byte record out; wall clock around the calls"}))
 
 

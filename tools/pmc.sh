@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --cpu-sample 0 --no-h2d $*"     # --no-h2d: the host-buffer leg launches the kernels over chunks of the batch, which would lower the per-launch means
+ARGS="--steps 3 --warmup 1 --cpu-sample 0 --no-h2d --no-stages $*"     # --no-h2d: the host-buffer leg launches the kernels over chunks of the batch, which would lower the per-launch means
 # PMC_CMD overrides the profiled command (default: the bench workload), e.g. PMC_CMD="python tools/stage_throughput.py 1024"
 CMD=${PMC_CMD:-"python $ROOT/bench.py $ARGS"}
 i=0

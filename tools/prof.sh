@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $ROOT/bench.py --steps 20 --warmup 3 --no-h2d --cpu-sample 0 "$@" > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $ROOT/bench.py --steps 20 --warmup 3 --no-h2d --no-stages --cpu-sample 0 "$@" > $OUT/log.txt 2>&1
 F=$(find $OUT -name "*kernel_stats.csv" | head -1)
 python - "$F" <<'PY'
 import csv, sys
