@@ -473,6 +473,12 @@ def main():
             out["poses_sha1"] = poses_sha1
             out["config"]["map_source"] = "built on rank 0, broadcast over the process group" if (world_size > 1 or force_coll) else "built on rank 0"
             out["config"]["process_group_backend"] = dist.get_backend() if use_dist else None
+        # fetched / algorithmic bytes of the LM solve per instantiation, from the committed PMC profiles
+        try:
+            with open(os.path.join(ROOT, "profiles", "r04_lm_traffic.json")) as f:
+                out["roofline"]["lm_instantiations"] = {k: v for k, v in json.load(f).items() if k != "note"}
+        except OSError:
+            out["roofline"]["lm_instantiations"] = None
         out["value_incl_h2d"] = None               # N=1 only: the host-buffer call is a separate, untimed-for-`value` leg
         if world_size == 1 and not args.no_h2d:
             v, ms, nbytes = host_buffer_rate(h, inp, B)
