@@ -25,26 +25,27 @@ __global__ void __launch_bounds__(256) pairs_arm_kernel(int* __restrict__ bbox, 
   if (i < 6 * n_pairs) bbox[i] = (i % 6) < 3 ? 0x7fffffff : (int)0x80000000;
 }
 
+// Launch geometry of the three per-point kernels: blockIdx.y = pair, blockIdx.x = a chunk of kPairChunk points inside the pair
+// (grid.x = the longest pair's chunk count; a pair's surplus workgroups leave at once).  A 1-D launch over the concatenated cloud
+// needs every wavefront to find its pair first (a binary search over the offsets: eight dependent loads before the point is even
+// requested), and that search, not the atomics, was what the first version of these kernels spent its time in.
+constexpr int kPairChunk = 1024;                   // points per workgroup: four per lane, their loads issued together
 __global__ void __launch_bounds__(256)
-pairs_bbox_kernel(const float4* __restrict__ pts, int n, const int* __restrict__ off, int n_pairs, int* __restrict__ bbox) {
+pairs_bbox_kernel(const float4* __restrict__ pts, const int* __restrict__ off, int* __restrict__ bbox) {
   __shared__ float s_mn[4][3], s_mx[4][3];
-  __shared__ int s_pair[2];
-  const int i = off[0] + blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in = i < off[0] + n;
-  const int p = in ? find_scan_wave(off, n_pairs, i) : -1;
-  if (threadIdx.x == 0) s_pair[0] = p;
-  const int last = min((int)(blockIdx.x * blockDim.x) + 255, n - 1);
-  if ((int)(blockIdx.x * blockDim.x + threadIdx.x) == last) s_pair[1] = p;
+  const int pp = blockIdx.y;
+  const int lo = off[pp] + (int)blockIdx.x * kPairChunk, hi = min(off[pp + 1], lo + kPairChunk);
+  if (lo >= hi) return;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  if (in) {
-    const float4 q = pts[i];
-    if (isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) { mn[0] = mx[0] = q.x; mn[1] = mx[1] = q.y; mn[2] = mx[2] = q.z; }
-  }
-  __syncthreads();
-  if (s_pair[0] != s_pair[1]) {                  // a workgroup across a pair boundary: every lane for itself
-    if (in && mn[0] != INFINITY)
-      for (int a = 0; a < 3; a++) { atomicMin(&bbox[6 * p + a], float_to_ordered(mn[a])); atomicMax(&bbox[6 * p + 3 + a], float_to_ordered(mx[a])); }
-    return;
+  float4 q[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const int i = lo + u * 256 + (int)threadIdx.x; q[u] = pts[min(i, hi - 1)]; }
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    if (lo + u * 256 + (int)threadIdx.x < hi && isfinite(q[u].x) && isfinite(q[u].y) && isfinite(q[u].z)) {
+      mn[0] = fminf(mn[0], q[u].x); mn[1] = fminf(mn[1], q[u].y); mn[2] = fminf(mn[2], q[u].z);
+      mx[0] = fmaxf(mx[0], q[u].x); mx[1] = fmaxf(mx[1], q[u].y); mx[2] = fmaxf(mx[2], q[u].z);
+    }
   }
 #pragma unroll
   for (int a = 0; a < 3; a++) {
@@ -54,7 +55,6 @@ pairs_bbox_kernel(const float4* __restrict__ pts, int n, const int* __restrict__
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) { for (int a = 0; a < 3; a++) { s_mn[wave][a] = mn[a]; s_mx[wave][a] = mx[a]; } }
   __syncthreads();
-  const int pp = s_pair[0];
   if (threadIdx.x < 3) {
     const int a = threadIdx.x;
     const float v = fminf(fminf(s_mn[0][a], s_mn[1][a]), fminf(s_mn[2][a], s_mn[3][a]));
@@ -76,22 +76,30 @@ pairs_desc_kernel(const int* __restrict__ bbox, int n_pairs, const int* __restri
 
 // one thread per map point of the concatenated clouds: its pair, its cell in that pair's grid
 __global__ void __launch_bounds__(256)
-pairs_count_kernel(const float4* __restrict__ pts, int n, const int* __restrict__ off, int n_pairs, const int* __restrict__ cell_base,
+pairs_count_kernel(const float4* __restrict__ pts, const int* __restrict__ off, const int* __restrict__ cell_base,
                    const GridDesc* __restrict__ gdesc, int* __restrict__ cell_of, int* __restrict__ count) {
-  const int i = off[0] + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= off[0] + n) return;
-  const int p = find_scan_wave(off, n_pairs, i);
+  const int p = blockIdx.y;
+  const int lo = off[p] + (int)blockIdx.x * kPairChunk, hi = min(off[p + 1], lo + kPairChunk);
+  if (lo >= hi) return;
   const GridDesc g = gdesc[p];
-  const float4 q = pts[i];
-  int c = -1;
-  if (isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) {
-    int cx = grid_coord(q.x, g.ox, g.inv_cell_x, g.dx); cx = min(max(cx, 0), g.dx - 1);
-    int cy = grid_coord(q.y, g.oy, g.inv_cell, g.dy); cy = min(max(cy, 0), g.dy - 1);
-    int cz = grid_coord(q.z, g.oz, g.inv_cell, g.dz); cz = min(max(cz, 0), g.dz - 1);
-    c = cell_base[p] + (cz * g.dy + cy) * g.dx + cx;
-    atomicAdd(&count[c], 1);
+  const int base = cell_base[p], o0 = off[0];
+  float4 q[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const int i = lo + u * 256 + (int)threadIdx.x; q[u] = pts[min(i, hi - 1)]; }
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int i = lo + u * 256 + (int)threadIdx.x;
+    if (i >= hi) break;
+    int c = -1;
+    if (isfinite(q[u].x) && isfinite(q[u].y) && isfinite(q[u].z)) {
+      int cx = grid_coord(q[u].x, g.ox, g.inv_cell_x, g.dx); cx = min(max(cx, 0), g.dx - 1);
+      int cy = grid_coord(q[u].y, g.oy, g.inv_cell, g.dy); cy = min(max(cy, 0), g.dy - 1);
+      int cz = grid_coord(q[u].z, g.oz, g.inv_cell, g.dz); cz = min(max(cz, 0), g.dz - 1);
+      c = base + (cz * g.dy + cy) * g.dx + cx;
+      atomicAdd(&count[c], 1);
+    }
+    cell_of[i - o0] = c;
   }
-  cell_of[i - off[0]] = c;
 }
 
 // cursor[] = the counts on entry, consumed back to zero (as grid_scatter_kernel); sorted / pos_of are indexed from the
