@@ -341,7 +341,14 @@ __device__ __forceinline__ int find_scan_off_wave(const int* __restrict__ off, i
 // 1 024 scans for 24 M points).  Halo slots outside the batch stay unread: the margin test keeps the window inside the scan.
 __global__ void __launch_bounds__(256) extract_curvature_kernel(ExtractView v, ExtractParams prm) {
   __shared__ float4 s_p[256 + 10];
-  const int g0 = blockIdx.x * 256, tid = threadIdx.x;
+  // blockIdx.y = scan, blockIdx.x = a 256-point tile of THAT scan (grid.x = the longest scan's tile count; surplus workgroups leave
+  // at once).  Launched 1-D over the concatenated batch, every wavefront had to binary-search its scan in the offset table first: ten
+  // dependent scalar loads in front of one point load and ~40 instructions of work (measured on the same pattern in the pairs
+  // index build: 205 -> 17 us, docs/kernels/pairs.md).
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int o = v.off[b];
+  if ((int)blockIdx.x * 256 >= v.off[b + 1] - o) return;
+  const int g0 = o + (int)blockIdx.x * 256;
   const int g = g0 + tid;
   if (g < v.n_total) s_p[tid + 5] = v.full_pts[g];
   if (tid < 10) {
@@ -350,8 +357,6 @@ __global__ void __launch_bounds__(256) extract_curvature_kernel(ExtractView v, E
   }
   __syncthreads();
   if (g >= v.n_total) return;
-  const int b = find_scan_off_wave(v.off, v.n_scans, g);
-  const int o = v.off[b];
   const int i = g - o;
   const int N = v.n_full[b];
   if (i >= N) return;
