@@ -131,3 +131,23 @@ def register_sharded(register_fn, corner, corner_off, surf, surf_off, guesses):
     s = torch.as_tensor(np.asarray(status, dtype=np.int32).reshape(-1))
     gp, gs = gather_ragged(p, s, B)
     return gp.numpy(), gs.numpy()
+
+
+def register_pairs_sharded(register_fn, map_corner, map_corner_off, map_surf, map_surf_off, corner, corner_off, surf, surf_off, guesses):
+    """"Many map-submap pairs" across GPUs: the P pairs are block-partitioned over the ranks, every rank indexes and
+    registers ITS pairs only -- nothing is broadcast, the maps never leave the rank that owns them -- and the poses are gathered in pair
+    order.  `register_fn(map_corner, mc_off, map_surf, ms_off, corner, c_off, surf, s_off, guesses) -> (poses (p,7), status (p,))` is
+    capi.Handle.match_pairs_batch in production."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    P = len(guesses)
+    lo, hi = shard_bounds(P, rank, world)
+    mco, (a0, a1) = shard_offsets(map_corner_off, lo, hi)
+    mso, (b0, b1) = shard_offsets(map_surf_off, lo, hi)
+    co, (c0, c1) = shard_offsets(corner_off, lo, hi)
+    so, (s0, s1) = shard_offsets(surf_off, lo, hi)
+    poses, status = register_fn(map_corner[a0:a1], mco, map_surf[b0:b1], mso, corner[c0:c1], co, surf[s0:s1], so, guesses[lo:hi])[:2]
+    p = torch.as_tensor(np.asarray(poses, dtype=np.float64).reshape(-1, 7))
+    s = torch.as_tensor(np.asarray(status, dtype=np.int32).reshape(-1))
+    gp, gs = gather_ragged(p, s, P)
+    return gp.numpy(), gs.numpy()

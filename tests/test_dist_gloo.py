@@ -57,6 +57,50 @@ def test_sharded_registration_equals_single_process(oracle):
     assert np.array_equal(ret["eq"], want[:4])
 
 
+def _pairs_case(orc, P=5):
+    """P pairs with different (thinned) maps of the small world."""
+    rng = np.random.default_rng(3)
+    _, mc, ms = common.small_world(20000)
+    mcs, mss, cs, ss, gs = [], [], [], [], []
+    for k, (pts, ring, truth, guess) in enumerate(common.scans(P, 20000)):
+        _, corner, surf = common.features_from_oracle(orc, pts, ring)
+        mcs.append(mc[rng.uniform(size=len(mc)) < 0.9]); mss.append(ms[rng.uniform(size=len(ms)) < 0.7 + 0.05 * k])
+        cs.append(corner); ss.append(surf); gs.append(guess)
+    cat = lambda ls: (np.concatenate(ls), np.cumsum([0] + [len(a) for a in ls]).astype(np.int32))   # noqa: E731
+    return cat(mcs), cat(mss), cat(cs), cat(ss), np.stack(gs)
+
+
+def _oracle_pairs(orc):
+    def fn(mc, mco, ms, mso, c, co, s, so, g):
+        poses, status = [], []
+        for p in range(len(g)):
+            rc, pose, _ = orc.match_scan2map(mc[mco[p]:mco[p + 1]], ms[mso[p]:mso[p + 1]], c[co[p]:co[p + 1]], s[so[p]:so[p + 1]], g[p])
+            poses.append(pose); status.append(rc)
+        return np.array(poses).reshape(-1, 7), np.array(status, np.int32)
+    return fn
+
+
+def _pairs_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    (mc, mco), (ms, mso), (c, co), (s, so), g = _pairs_case(orc)
+    poses, status = mdist.register_pairs_sharded(_oracle_pairs(orc), mc, mco, ms, mso, c, co, s, so, g)
+    if rank == 0:
+        ret["poses"] = poses; ret["status"] = status
+    dist.destroy_process_group()
+
+
+def test_sharded_pairs_equal_single_process(oracle):
+    """"Many map-submap pairs" sharded over two ranks (5 pairs: 3 + 2): every rank registers its own pairs against its own maps,
+    nothing is broadcast, the gathered poses equal the unsharded run bit for bit."""
+    (mc, mco), (ms, mso), (c, co), (s, so), g = _pairs_case(oracle)
+    want, st = _oracle_pairs(oracle)(mc, mco, ms, mso, c, co, s, so, g)
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_pairs_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert np.array_equal(ret["poses"], want) and np.array_equal(ret["status"], st)
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 5, 8, 1024, 1031):
         for w in (1, 2, 3, 8):
