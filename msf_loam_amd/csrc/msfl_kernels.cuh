@@ -232,18 +232,46 @@ __device__ __forceinline__ void top5_init(Top5& t, float bound) {
 }
 __device__ __forceinline__ float top5_d4(const Top5& t) { return __uint_as_float((unsigned int)(t.k4 >> 32)); }  // the gate while < 5 found
 
+#ifndef MSFL_TOP5_SELECT
+#define MSFL_TOP5_SELECT 0          /* 1: the compare / select insertion network of rounds 1-3 (A/B) */
+#endif
+// unsigned 64-bit min / max of two keys whose high words are < 2^31, on the f64 min / max unit (see top5_insert)
+__device__ __forceinline__ unsigned long long u64_min_f(unsigned long long a, unsigned long long b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+  return (unsigned long long)__double_as_longlong(r);
+}
+__device__ __forceinline__ unsigned long long u64_max_f(unsigned long long a, unsigned long long b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+  return (unsigned long long)__double_as_longlong(r);
+}
 __device__ __forceinline__ void top5_insert(Top5& t, float d, int idx) {
   // cheap pre-filter on the distance word alone (a full-rate 32-bit compare; the bit pattern of a
   // non-negative float is monotone), then the exact 64-bit (distance, index) order
   if (__float_as_uint(d) > (unsigned int)(t.k4 >> 32)) return;
   const unsigned long long x = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)idx;
   if (!(x < t.k4)) return;
+#if MSFL_TOP5_SELECT
   const bool c3 = x < t.k3, c2 = x < t.k2, c1 = x < t.k1, c0 = x < t.k0;
   t.k4 = c3 ? t.k3 : x;
   t.k3 = c3 ? (c2 ? t.k2 : x) : t.k3;
   t.k2 = c2 ? (c1 ? t.k1 : x) : t.k2;
   t.k1 = c1 ? (c0 ? t.k0 : x) : t.k1;
   t.k0 = c0 ? x : t.k0;
+#else
+  // Sorted insertion as a min / max chain on the keys READ AS DOUBLES.  A key's high word is the bit pattern of a non-negative f32
+  // (< 2^31), so as an f64 it is a non-negative finite number or denormal (exponent field = the top 11 bits of the f32 pattern:
+  // <= 0x7fc even for an f32 NaN), and for non-negative doubles the IEEE order IS the unsigned order of the bit patterns; f64
+  // denormals are preserved (the default f64 mode), min / max select one operand bit for bit.  8 instructions instead of
+  // 5 x v_cmp_lt_u64 + 16 x v_cndmask_b32 (all of the 4-clock class): the insertion pass runs for the whole wavefront whenever one
+  // lane inserts and was ~30 % of the kernel.
+  const unsigned long long c0 = u64_max_f(t.k0, x); t.k0 = u64_min_f(t.k0, x);
+  const unsigned long long c1 = u64_max_f(t.k1, c0); t.k1 = u64_min_f(t.k1, c0);
+  const unsigned long long c2 = u64_max_f(t.k2, c1); t.k2 = u64_min_f(t.k2, c1);
+  const unsigned long long c3 = u64_max_f(t.k3, c2); t.k3 = u64_min_f(t.k3, c2);
+  t.k4 = c3;                    // = min(k4, c3): x < k4 (the guard above) and k3 <= k4, so the largest of {k0..k3, x} is below k4
+#endif
 }
 
 // flann::L2_Simple<float>: ((dx*dx) + dy*dy) + dz*dz, every operation rounded to f32
