@@ -171,12 +171,12 @@ def valu_roof(kernel_prefix, launch_ms):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pt = json.load(f)
-        with open(os.path.join(ROOT, "profiles", "r03_valu_mix.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_valu_mix.json")) as f:
             mix = json.load(f)
     except OSError:
         return None
     hit = [k for k in pt["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>") and "sq_insts_valu" in pt["kernels"][k]]
-    mk = [k for k in mix["kernels"] if k.replace(" ", "") in (kernel_prefix, kernel_prefix + "<false,false>", kernel_prefix + "_split_kernel", kernel_prefix + "<128>")] or \
+    mk = [k for k in mix["kernels"] if k.replace(" ", "") in (kernel_prefix, kernel_prefix + "<false>", kernel_prefix + "<false,false>", kernel_prefix + "_split_kernel", kernel_prefix + "<128>")] or \
          [k for k in mix["kernels"] if k.startswith(kernel_prefix) and not k.replace(" ", "").endswith(",true>")]
     if not hit or not mk or launch_ms <= 0:
         return None
@@ -187,7 +187,7 @@ def valu_roof(kernel_prefix, launch_ms):
     return {"wave_insts_per_launch": insts, "clocks_per_inst": clk, "clocks_per_inst_class": mix["clocks"],
             "static_mix": {"fast_2clk": m["fast_2clk"], "four_clk": m["four_clk"], "slow": m["slow"]},
             "simd_clocks_needed": insts * clk, "simd_clocks_available": simd_clocks, "frac": insts * clk / simd_clocks,
-            "source": "SQ_INSTS_VALU: %s; mix: profiles/r03_valu_mix.json (static ISA counts); rates: profiles/r03_valu_rate.md; "
+            "source": "SQ_INSTS_VALU: %s; mix: profiles/r04_valu_mix.json (static ISA counts); rates: profiles/r03_valu_rate.md; "
                       "clock 2.4 GHz x 256 CUs x 4 SIMDs" % pt["source"].split(" (")[0]}
 
 
