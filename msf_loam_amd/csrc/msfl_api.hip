@@ -238,6 +238,8 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // box would need more (larger cells stay exact).
 msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi, const int* n_dev = nullptr) {
   ScopedTimer timer(h, T_INDEX);
+  // the 5-NN walk addresses candidates by 32-bit byte offsets into the sorted copy (knn5_grid_k32)
+  if (n >= (1 << 28)) return fail(h, MSFL_BAD_ARG, "map cloud of 2^28 points or more (the index addresses 16-byte points by 32-bit byte offsets)");
   mi.n_input = n;
   hipStream_t st = h->stream;
   // span of the dense cell table: what the previous build of this map said it needs (+25 %), else 1 M

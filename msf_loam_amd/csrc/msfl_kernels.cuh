@@ -231,6 +231,7 @@ __device__ __forceinline__ void top5_init(Top5& t, float bound) {
   t.k0 = t.k1 = t.k2 = t.k3 = t.k4 = ((unsigned long long)__float_as_uint(bound) << 32) | 0xffffffffull;
 }
 __device__ __forceinline__ float top5_d4(const Top5& t) { return __uint_as_float((unsigned int)(t.k4 >> 32)); }  // the gate while < 5 found
+__device__ __forceinline__ float top_d4(const Top5& t) { return top5_d4(t); }
 
 #ifndef MSFL_TOP5_SELECT
 #define MSFL_TOP5_SELECT 0          /* 1: the compare / select insertion network of rounds 1-3 (A/B) */
@@ -274,6 +275,52 @@ __device__ __forceinline__ void top5_insert(Top5& t, float d, int idx) {
 #endif
 }
 
+// Round 4, the walk's own top list: SIX 32-bit keys (distance bits & ~7) | slot, sorted, and the candidates' positions in the
+// sorted map kept per (slot, lane) in LDS.  A candidate that passes the pre-filter takes the slot of the key it can only evict
+// (the 6th), stores its position there and goes through 1 x v_min_u32 + 5 x v_med3_u32 — ~45 clocks per insertion pass of the
+// wavefront instead of ~78 for the 64-bit min / max chain above (the pass runs for all 64 lanes whenever one lane inserts:
+// ~47 passes per wavefront).  The keys order candidates by their distance truncated to 29 bits (t = bits >> 3); the result is
+// the exact top-5 by (distance, index) whenever the six final keys have six different t:
+//  * a candidate dropped at the pre-filter had t > t(5th at that time) >= t(final 5th);
+//  * every other candidate was offered to the list, which keeps the six smallest keys offered, so a candidate outside the final
+//    top-5 with t == t(final 5th) implies t(final 6th) == t(final 5th);
+//  * with different t the truncated order IS the order of the exact distances, and the index word is never consulted.
+// A lane whose final keys show an equal-t neighbour pair (or whose 5th shares its t with the acceptance gate) is AMBIGUOUS and
+// is searched again with the exact 64-bit keys (Top5): two distances within 2^-21 relative of each other, ~1e-6 of the queries
+// on a scanned surface, every query on an exact lattice.  The 6th key's stored position may be stale (a candidate that tied
+// with it overwrote the slot without entering); the 6th is never output and can only leave the list.
+#ifndef MSFL_KNN_KEY32
+#define MSFL_KNN_KEY32 1            /* 0: the 64-bit (distance, index) keys of rounds 1-4a in every kernel (A/B) */
+#endif
+constexpr unsigned int kTopSentinel = 0xffffff00u;      // sentinels 0xffffff00 + 9 i: six different t, slots 0..5, above every f32 distance pattern
+// k = med3(below, k, x) IN PLACE (below <= k): the sorted list's element after x has been inserted somewhere
+__device__ __forceinline__ void u32_med3_into(unsigned int& k, unsigned int below, unsigned int x) {
+  asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k) : "v"(below), "v"(x));
+}
+struct Top6K {
+  unsigned int k0, k1, k2, k3, k4, k5;
+  unsigned int bound;               // min(k4 | 7, gate bits): the pre-filter, a conservative 5th distance for the row / cell bounds
+  unsigned int gate;                // acceptance gate bits (or the seeded initial bound)
+  int* col;                         // this lane's column of the slot table: col[slot * kTopSlotStride]
+};
+constexpr int kTopSlots = 6;
+__device__ __forceinline__ void top_init(Top6K& t, float bound, int* col) {
+  t.k0 = kTopSentinel; t.k1 = kTopSentinel + 9; t.k2 = kTopSentinel + 18; t.k3 = kTopSentinel + 27; t.k4 = kTopSentinel + 36; t.k5 = kTopSentinel + 45;
+  t.gate = __float_as_uint(bound); t.bound = t.gate; t.col = col;
+}
+__device__ __forceinline__ float top_d4(const Top6K& t) { return __uint_as_float(t.bound); }
+// true: the five nearest and their order are decided by the truncated keys (see above); false: search again with Top5
+__device__ __forceinline__ bool top_settled(const Top6K& t, float accept_gate) {
+  const unsigned int amb = min(min(min(t.k0 ^ t.k1, t.k1 ^ t.k2), min(t.k2 ^ t.k3, t.k3 ^ t.k4)), min(t.k4 ^ t.k5, t.k4 ^ __float_as_uint(accept_gate)));
+  return amb >= 8u;
+}
+__device__ __forceinline__ bool top_found(const Top6K& t) { return t.k4 < kTopSentinel; }     // five real candidates within the gate
+template <int STRIDE>
+__device__ __forceinline__ int top_pos(const Top6K& t, unsigned int k) { return (int)((unsigned int)t.col[(k & 7u) * STRIDE] >> 4); }   // stored: byte offset
+
+template <int STRIDE>
+__device__ __forceinline__ void top_insert(Top5& t, float d, int idx, int) { top5_insert(t, d, idx); }
+
 // flann::L2_Simple<float>: ((dx*dx) + dy*dy) + dz*dz, every operation rounded to f32
 __device__ __forceinline__ float l2_simple(float4 a, float3 q) {
   const float dx = a.x - q.x, dy = a.y - q.y, dz = a.z - q.z;
@@ -307,10 +354,12 @@ __device__ __forceinline__ float axis_gap(float u, int c) {
 
 // max_sq_dist here is the INITIAL bound of the search: the acceptance gate, or (second outer iteration) something tighter
 // that five real map points are known to meet (knn5_seed_bound).
+// TOP: Top5 (exact 64-bit keys) or Top6K (32-bit keys + slot table with lane stride STRIDE ints, exact unless !top_settled); the caller
+// initialises it with the search's initial bound.
+template <class TOP, int STRIDE = 64>
 __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __restrict__ sorted,
-                                          const int* __restrict__ cell_start, float3 q, float max_sq_dist, Top5& t,
+                                          const int* __restrict__ cell_start, float3 q, TOP& t,
                                           int& n_cand) {      // n_cand: candidates evaluated (dead code unless the caller reads it)
-  top5_init(t, max_sq_dist);
   const float ux = (q.x - g.ox) * g.inv_cell_x, uy = (q.y - g.oy) * g.inv_cell, uz = (q.z - g.oz) * g.inv_cell;
   const int cx = grid_coord(q.x, g.ox, g.inv_cell_x, g.dx);
   const int cy = grid_coord(q.y, g.oy, g.inv_cell, g.dy);
@@ -349,16 +398,17 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
     n_cand += e - s;
     const float4* p = sorted + s;
     const float4* const pe = sorted + e;
-    for (; p + 1 < pe; p += 2) {            // two loads in flight, one address register
+    int pos = s;                            // position in the sorted map (Top6K's payload; dead code for Top5)
+    for (; p + 1 < pe; p += 2, pos += 2) {  // two loads in flight, one address register
       float4 m0 = p[0], m1 = p[1];
       // keep the index word in the 16-byte load: left alone, the compiler splits it off into a second,
       // dependent load inside the (latency-critical) insertion path
       asm volatile("" : "+v"(m0.w));
-      top5_insert(t, l2_simple_pk(m0, qxy, q.z), __float_as_int(m0.w));
+      top_insert<STRIDE>(t, l2_simple_pk(m0, qxy, q.z), __float_as_int(m0.w), pos);
       asm volatile("" : "+v"(m1.w));
-      top5_insert(t, l2_simple_pk(m1, qxy, q.z), __float_as_int(m1.w));
+      top_insert<STRIDE>(t, l2_simple_pk(m1, qxy, q.z), __float_as_int(m1.w), pos + 1);
     }
-    if (p < pe) { float4 m = p[0]; asm volatile("" : "+v"(m.w)); top5_insert(t, l2_simple_pk(m, qxy, q.z), __float_as_int(m.w)); }
+    if (p < pe) { float4 m = p[0]; asm volatile("" : "+v"(m.w)); top_insert<STRIDE>(t, l2_simple_pk(m, qxy, q.z), __float_as_int(m.w), pos); }
   };
 #pragma unroll
   for (int r = 0; r < 9; r++) {
@@ -379,7 +429,7 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
     if (y < 0 || y >= g.dy || z < 0 || z >= g.dz) continue;
     const float row2 = (gy * gy + gz * gz) * cell2;
     const int row = (z * g.dy + y) * g.dx;
-    const float d4 = top5_d4(t);
+    const float d4 = top_d4(t);
     if (row2 > d4) continue;                  // d4 is the acceptance gate until five neighbours are known
     // trim the x range: drop end cells whose lower bound exceeds the 5th-best distance
     // a cell is dropped when its lower bound exceeds d4; the bounds shrink towards the query, so count the
@@ -394,6 +444,109 @@ __device__ __forceinline__ void knn5_grid(const GridDesc& g, const float4* __res
     if (a > b) continue;                      // only near the grid border: every remaining cell is out of reach
     scan(row, a, b);
   }
+}
+
+// The same walk for Top6K, written for the instruction count (the kernel is VALU-issue bound: every wave instruction of a
+// visited row is paid 64 lanes wide).  Differences to knn5_grid, none of which changes the result:
+//  * candidates are addressed by 32-bit BYTE offsets from the (scalar) map base (saddr loads, 32-bit loop control; a map is
+//    < 2^28 points: msfl_set_map refuses more) and the slot table stores the byte offset (position = offset >> 4 at the end);
+//  * a row's end cells are trimmed by COUNTING the cells whose bound exceeds (5th distance - row bound): the per-side bounds
+//    are made monotone at set-up (a cell at or beyond the query's own cell gets 0), so the count is the leading run;
+//  * row validity (y, z inside the grid) and the row bases come from six set-up compares / two offsets instead of four
+//    compares and two 32-bit multiplies per row.
+template <int STRIDE>
+__device__ __forceinline__ void top_insert_off(Top6K& t, float d, unsigned int off) {
+  const unsigned int db = __float_as_uint(d);
+  if (db > t.bound) return;
+  const unsigned int slot = t.k5 & 7u;
+  const unsigned int x = (db & ~7u) | slot;
+  t.col[slot * STRIDE] = (int)off;
+  u32_med3_into(t.k5, t.k4, x); u32_med3_into(t.k4, t.k3, x); u32_med3_into(t.k3, t.k2, x);
+  u32_med3_into(t.k2, t.k1, x); u32_med3_into(t.k1, t.k0, x);
+  t.k0 = min(t.k0, x);
+  t.bound = min(t.k4 | 7u, t.gate);
+}
+template <int STRIDE>
+__device__ __forceinline__ void knn5_grid_k32(const GridDesc& g, const float4* __restrict__ sorted,
+                                              const int* __restrict__ cell_start, float3 q, Top6K& t, int& n_cand) {
+  const float ux = (q.x - g.ox) * g.inv_cell_x, uy = (q.y - g.oy) * g.inv_cell, uz = (q.z - g.oz) * g.inv_cell;
+  const int cx = grid_coord(q.x, g.ox, g.inv_cell_x, g.dx);
+  const int cy = grid_coord(q.y, g.oy, g.inv_cell, g.dy);
+  const int cz = grid_coord(q.z, g.oz, g.inv_cell, g.dz);
+  const int xs = max(cx - kGridXSub, 0), xe = min(cx + kGridXSub, g.dx - 1);
+  if (xs > xe) return;
+  const float cell2 = g.cell2, cellx2 = g.cellx2;
+  const float gy0 = axis_gap(uy, cy - 1), gy1 = axis_gap(uy, cy), gy2 = axis_gap(uy, cy + 1);
+  const float gz0 = axis_gap(uz, cz - 1), gz1 = axis_gap(uz, cz), gz2 = axis_gap(uz, cz + 1);
+  float gxa[kGridXSub], gxb[kGridXSub];       // outermost first, non-increasing
+#pragma unroll
+  for (int k = 0; k < kGridXSub; k++) {
+    const float ga = axis_gap(ux, xs + k), gb = axis_gap(ux, xe - k);
+    gxa[k] = xs + k < cx ? ga * ga * cellx2 : 0.0f;
+    gxb[k] = xe - k > cx ? gb * gb * cellx2 : 0.0f;
+  }
+  const msfl_f2 qxy = {q.x, q.y};
+  const bool y_lo = gy0 <= gy2, z_lo = gz0 <= gz2;                 // near side: the smaller gap
+  const float g_ny = y_lo ? gy0 : gy2, g_fy = y_lo ? gy2 : gy0;
+  const float g_nz = z_lo ? gz0 : gz2, g_fz = z_lo ? gz2 : gz0;
+  const float q_ny = g_ny * g_ny, q_fy = g_fy * g_fy, q_nz = g_nz * g_nz, q_fz = g_fz * g_fz, q_y1 = gy1 * gy1, q_z1 = gz1 * gz1;
+  const bool ny_first = g_ny <= g_nz, fy_first = g_fy <= g_fz;
+  const bool e_first = q_ny + q_fz <= q_fy + q_nz;                 // (near y, far z) before (far y, near z)
+  // validity of the three y and three z cell coordinates, near / centre / far
+  const int sy = y_lo ? -1 : 1, sz = z_lo ? -1 : 1;
+  const bool v_y1 = (unsigned int)cy < (unsigned int)g.dy, v_ny = (unsigned int)(cy + sy) < (unsigned int)g.dy, v_fy = (unsigned int)(cy - sy) < (unsigned int)g.dy;
+  const bool v_z1 = (unsigned int)cz < (unsigned int)g.dz, v_nz = (unsigned int)(cz + sz) < (unsigned int)g.dz, v_fz = (unsigned int)(cz - sz) < (unsigned int)g.dz;
+  const int base0 = (cz * g.dy + cy) * g.dx;                       // only used where the row is valid
+  const int off_y = y_lo ? -g.dx : g.dx;                           // near-side steps
+  const int zstep = g.dy * g.dx;
+  const int off_z = z_lo ? -zstep : zstep;
+  const char* const mapb = (const char*)sorted;
+  auto visit = [&](bool valid, int row, float rowq) __attribute__((always_inline)) {
+    const float row2 = rowq * cell2;
+    const float d4 = top_d4(t);
+    if (!valid || row2 > d4) return;           // d4: the acceptance gate until five neighbours are known, then >= the 5th distance
+    const float room = d4 - row2;
+    int a = xs, b = xe;
+#pragma unroll
+    for (int k = 0; k < kGridXSub; k++) { a += gxa[k] > room ? 1 : 0; b -= gxb[k] > room ? 1 : 0; }
+    if (a > b) return;
+    const unsigned int s = (unsigned int)cell_start[(unsigned int)(row + a)], e = (unsigned int)cell_start[(unsigned int)(row + b + 1)];
+    if (s == e) return;
+    n_cand += (int)(e - s);
+    unsigned int off = s << 4;
+    const unsigned int end = e << 4, last = end - 16u;      // last: offset of the range's last point (>= off)
+    for (; off < last; off += 32u) {           // two loads in flight
+      float4 m0 = *(const float4*)(mapb + off), m1 = *(const float4*)(mapb + off + 16u);
+      asm volatile("" : "+v"(m0.w));           // keep the 16-byte loads (12-byte loads measured slower, rounds 1-2)
+      top_insert_off<STRIDE>(t, l2_simple_pk(m0, qxy, q.z), off);
+      asm volatile("" : "+v"(m1.w));
+      top_insert_off<STRIDE>(t, l2_simple_pk(m1, qxy, q.z), off + 16u);
+    }
+    if (off < end) { float4 m = *(const float4*)(mapb + off); asm volatile("" : "+v"(m.w)); top_insert_off<STRIDE>(t, l2_simple_pk(m, qxy, q.z), off); }
+  };
+  // the same per-query row order as knn5_grid: centre, near sides (smaller gap first), far sides, near-near, mixed diagonals, far-far
+  visit(v_y1 && v_z1, base0, q_y1 + q_z1);
+  {
+    const bool va = v_ny && v_z1, vb = v_y1 && v_nz;               // A: near-y side row, B: near-z side row
+    const float ra = q_ny + q_z1, rb = q_y1 + q_nz;
+    visit(ny_first ? va : vb, base0 + (ny_first ? off_y : off_z), ny_first ? ra : rb);
+    visit(ny_first ? vb : va, base0 + (ny_first ? off_z : off_y), ny_first ? rb : ra);
+  }
+  {
+    const bool va = v_fy && v_z1, vb = v_y1 && v_fz;
+    const float ra = q_fy + q_z1, rb = q_y1 + q_fz;
+    visit(fy_first ? va : vb, base0 - (fy_first ? off_y : off_z), fy_first ? ra : rb);
+    visit(fy_first ? vb : va, base0 - (fy_first ? off_z : off_y), fy_first ? rb : ra);
+  }
+  visit(v_ny && v_nz, base0 + off_y + off_z, q_ny + q_nz);
+  {
+    const bool va = v_ny && v_fz, vb = v_fy && v_nz;               // A: (near y, far z)
+    const float ra = q_ny + q_fz, rb = q_fy + q_nz;
+    const int oa = off_y - off_z, ob = off_z - off_y;
+    visit(e_first ? va : vb, base0 + (e_first ? oa : ob), e_first ? ra : rb);
+    visit(e_first ? vb : va, base0 + (e_first ? ob : oa), e_first ? rb : ra);
+  }
+  visit(v_fy && v_fz, base0 - off_y - off_z, q_fy + q_fz);
 }
 
 // Second outer iteration (mapping_scan_matcher.cc:75: the association loop runs kOptimalNum = 2 times on the same clouds): the five
@@ -581,8 +734,9 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   Top5 t;
   int n_cand = 0;
   const float bound = SEED ? knn5_seed_bound(is_edge ? map_c : map_s, out, q, max_sq_dist) : max_sq_dist;
-  if (is_edge) { const GridDesc gc = gcp[PAIRS ? b : 0]; knn5_grid(gc, map_c, cs_c + (PAIRS ? cbase_c[b] : 0), q, bound, t, n_cand); }
-  else { const GridDesc gs = gsp[PAIRS ? b : 0]; knn5_grid(gs, map_s, cs_s + (PAIRS ? cbase_s[b] : 0), q, bound, t, n_cand); }
+  top5_init(t, bound);
+  if (is_edge) { const GridDesc gc = gcp[PAIRS ? b : 0]; knn5_grid(gc, map_c, cs_c + (PAIRS ? cbase_c[b] : 0), q, t, n_cand); }
+  else { const GridDesc gs = gsp[PAIRS ? b : 0]; knn5_grid(gs, map_s, cs_s + (PAIRS ? cbase_s[b] : 0), q, t, n_cand); }
   if (COUNT) {                                                  // one atomic per wavefront: sum over the lanes still here
     const unsigned long long act = __ballot(1);
     unsigned long long m = act;
@@ -606,7 +760,7 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
 template <bool EDGE, bool SEED>
 __device__ __forceinline__ void knn5_one_kind(const BatchView& bv, const double* __restrict__ poses, const int* __restrict__ status,
                                               const GridDesc* __restrict__ gp, const float4* __restrict__ map, const int* __restrict__ cs,
-                                              const int* __restrict__ po, float max_sq_dist, int* __restrict__ nn, int block) {
+                                              const int* __restrict__ po, float max_sq_dist, int* __restrict__ nn, int block, int* s_slot) {
   const int* off = EDGE ? bv.corner_off : bv.surf_off;
   const int f_i = off[0] + block * (int)blockDim.x + (int)threadIdx.x;
   if (f_i >= off[bv.n_scans]) return;
@@ -618,10 +772,27 @@ __device__ __forceinline__ void knn5_one_kind(const BatchView& bv, const double*
   const float4 f = EDGE ? bv.corner[f_i] : bv.surf[f_i];
   const pose7 T = load_pose(poses + 7 * b);
   const float3 q = transform_point_f32(T, f.x, f.y, f.z);                          // :123 / :193
-  Top5 t;
   int n_cand = 0;
   const GridDesc gd = *gp;
-  knn5_grid(gd, map, cs, q, SEED ? knn5_seed_bound(map, out, q, max_sq_dist) : max_sq_dist, t, n_cand);
+  const float bound = SEED ? knn5_seed_bound(map, out, q, max_sq_dist) : max_sq_dist;
+#if MSFL_KNN_KEY32
+  Top6K tk;
+  top_init(tk, bound, s_slot + threadIdx.x);
+  knn5_grid_k32<kAssocBlock>(gd, map, cs, q, tk, n_cand);
+  if (top_settled(tk, max_sq_dist)) {
+    if (top_found(tk)) {                                                              // :128 / :198: the 5th is below the gate (t differs from the gate's)
+      out[0] = top_pos<kAssocBlock>(tk, tk.k0); out[1] = top_pos<kAssocBlock>(tk, tk.k1); out[2] = top_pos<kAssocBlock>(tk, tk.k2);
+      out[3] = top_pos<kAssocBlock>(tk, tk.k3); out[4] = top_pos<kAssocBlock>(tk, tk.k4);   // nearest first, positions in the sorted map
+    } else {
+      out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1;
+    }
+    return;
+  }
+  // ambiguous under the truncated keys: the exact (distance, index) search
+#endif
+  Top5 t;
+  top5_init(t, bound);
+  knn5_grid(gd, map, cs, q, t, n_cand);
   if ((unsigned int)t.k4 != 0xffffffffu && (double)top5_d4(t) < (double)max_sq_dist) {      // :128 / :198
     out[0] = po[(unsigned int)t.k0]; out[1] = po[(unsigned int)t.k1]; out[2] = po[(unsigned int)t.k2];
     out[3] = po[(unsigned int)t.k3]; out[4] = po[(unsigned int)t.k4];       // nearest first
@@ -635,8 +806,9 @@ knn5_scan2map_split_kernel(BatchView bv, const double* __restrict__ poses, const
                            const GridDesc* __restrict__ gcp, const float4* __restrict__ map_c, const int* __restrict__ cs_c,
                            const GridDesc* __restrict__ gsp, const float4* __restrict__ map_s, const int* __restrict__ cs_s,
                            const int* __restrict__ pos_c, const int* __restrict__ pos_s, float max_sq_dist, int* __restrict__ nn, int edge_blocks) {
-  if ((int)blockIdx.x < edge_blocks) knn5_one_kind<true, SEED>(bv, poses, status, gcp, map_c, cs_c, pos_c, max_sq_dist, nn, (int)blockIdx.x);
-  else knn5_one_kind<false, SEED>(bv, poses, status, gsp, map_s, cs_s, pos_s, max_sq_dist, nn, (int)blockIdx.x - edge_blocks);
+  __shared__ int s_slot[MSFL_KNN_KEY32 ? kTopSlots * kAssocBlock : 1];        // Top6K's slot table: 6 positions per lane
+  if ((int)blockIdx.x < edge_blocks) knn5_one_kind<true, SEED>(bv, poses, status, gcp, map_c, cs_c, pos_c, max_sq_dist, nn, (int)blockIdx.x, s_slot);
+  else knn5_one_kind<false, SEED>(bv, poses, status, gsp, map_s, cs_s, pos_s, max_sq_dist, nn, (int)blockIdx.x - edge_blocks, s_slot);
 }
 
 // K4a, latency form: the same exact 5-NN for a launch too small to fill the machine (one scan per call: ~5 000 queries are
