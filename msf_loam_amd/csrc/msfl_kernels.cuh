@@ -289,6 +289,9 @@ __device__ __forceinline__ void top5_insert(Top5& t, float d, int idx) {
 // is searched again with the exact 64-bit keys (Top5): two distances within 2^-21 relative of each other, ~1e-6 of the queries
 // on a scanned surface, every query on an exact lattice.  The 6th key's stored position may be stale (a candidate that tied
 // with it overwrote the slot without entering); the 6th is never output and can only leave the list.
+#ifndef MSFL_KNN_PREFETCH
+#define MSFL_KNN_PREFETCH 0         /* 1: the k32 walk requests the next candidate pair before working on the current one */
+#endif
 #ifndef MSFL_KNN_KEY32
 #define MSFL_KNN_KEY32 1            /* 0: the 64-bit (distance, index) keys of rounds 1-4a in every kernel (A/B) */
 #endif
@@ -466,9 +469,19 @@ __device__ __forceinline__ void top_insert_off(Top6K& t, float d, unsigned int o
   t.k0 = min(t.k0, x);
   t.bound = min(t.k4 | 7u, t.gate);
 }
+#ifndef MSFL_KNN_X3
+#define MSFL_KNN_X3 0               /* 1: let the k32 walk load 12 bytes per candidate (the index word is not used there) */
+#endif
+#if MSFL_KNN_X3
+typedef float msfl_f3 __attribute__((ext_vector_type(3)));      // 16-byte aligned, loaded as global_load_dwordx3
+#define MSFL_PIN_W(m)
+#else
+#define MSFL_PIN_W(m) asm volatile("" : "+v"(m.w))
+#endif
 template <int STRIDE>
 __device__ __forceinline__ void knn5_grid_k32(const GridDesc& g, const float4* __restrict__ sorted,
-                                              const int* __restrict__ cell_start, float3 q, Top6K& t, int& n_cand) {
+                                              const int* __restrict__ cell_start, float3 q, Top6K& t, int& n_cand,
+                                              int cell_base = 0) {        // cell_base: this map's slice of a shared cell table (pairs)
   const float ux = (q.x - g.ox) * g.inv_cell_x, uy = (q.y - g.oy) * g.inv_cell, uz = (q.z - g.oz) * g.inv_cell;
   const int cx = grid_coord(q.x, g.ox, g.inv_cell_x, g.dx);
   const int cy = grid_coord(q.y, g.oy, g.inv_cell, g.dy);
@@ -496,7 +509,7 @@ __device__ __forceinline__ void knn5_grid_k32(const GridDesc& g, const float4* _
   const int sy = y_lo ? -1 : 1, sz = z_lo ? -1 : 1;
   const bool v_y1 = (unsigned int)cy < (unsigned int)g.dy, v_ny = (unsigned int)(cy + sy) < (unsigned int)g.dy, v_fy = (unsigned int)(cy - sy) < (unsigned int)g.dy;
   const bool v_z1 = (unsigned int)cz < (unsigned int)g.dz, v_nz = (unsigned int)(cz + sz) < (unsigned int)g.dz, v_fz = (unsigned int)(cz - sz) < (unsigned int)g.dz;
-  const int base0 = (cz * g.dy + cy) * g.dx;                       // only used where the row is valid
+  const int base0 = (cz * g.dy + cy) * g.dx + cell_base;           // only used where the row is valid
   const int off_y = y_lo ? -g.dx : g.dx;                           // near-side steps
   const int zstep = g.dy * g.dx;
   const int off_z = z_lo ? -zstep : zstep;
@@ -515,14 +528,37 @@ __device__ __forceinline__ void knn5_grid_k32(const GridDesc& g, const float4* _
     n_cand += (int)(e - s);
     unsigned int off = s << 4;
     const unsigned int end = e << 4, last = end - 16u;      // last: offset of the range's last point (>= off)
-    for (; off < last; off += 32u) {           // two loads in flight
-      float4 m0 = *(const float4*)(mapb + off), m1 = *(const float4*)(mapb + off + 16u);
-      asm volatile("" : "+v"(m0.w));           // keep the 16-byte loads (12-byte loads measured slower, rounds 1-2)
+#if MSFL_KNN_PREFETCH
+    // software pipeline: the next pair is requested before the current one is worked on (four loads in flight; a lane's walk is a
+    // chain of load round trips and eight wavefronts per SIMD is all there is to hide them).  The pair after a range's end is
+    // requested and dropped: the sorted copy is allocated with four points of slack.  The odd tail is already in m0.
+    float4 m0 = *(const float4*)(mapb + off), m1 = *(const float4*)(mapb + off + 16u);
+#pragma unroll 2
+    while (off < last) {
+      const unsigned int nx = off + 32u;
+      float4 n0 = *(const float4*)(mapb + nx), n1 = *(const float4*)(mapb + nx + 16u);
+      MSFL_PIN_W(m0);           // keep the 16-byte loads (12-byte loads measured slower, rounds 1-2)
       top_insert_off<STRIDE>(t, l2_simple_pk(m0, qxy, q.z), off);
-      asm volatile("" : "+v"(m1.w));
+      MSFL_PIN_W(m1);
+      top_insert_off<STRIDE>(t, l2_simple_pk(m1, qxy, q.z), off + 16u);
+      m0 = n0; m1 = n1; off = nx;
+    }
+    if (off == last) { MSFL_PIN_W(m0); top_insert_off<STRIDE>(t, l2_simple_pk(m0, qxy, q.z), off); }
+#else
+#if MSFL_KNN_X3
+#define MSFL_LD(o) ([&]() { const msfl_f3 v = *(const msfl_f3*)(mapb + (o)); return make_float4(v.x, v.y, v.z, 0.0f); }())
+#else
+#define MSFL_LD(o) (*(const float4*)(mapb + (o)))
+#endif
+    for (; off < last; off += 32u) {           // two loads in flight
+      float4 m0 = MSFL_LD(off), m1 = MSFL_LD(off + 16u);
+      MSFL_PIN_W(m0);           // keep the 16-byte loads (12-byte loads measured slower, rounds 1-2)
+      top_insert_off<STRIDE>(t, l2_simple_pk(m0, qxy, q.z), off);
+      MSFL_PIN_W(m1);
       top_insert_off<STRIDE>(t, l2_simple_pk(m1, qxy, q.z), off + 16u);
     }
-    if (off < end) { float4 m = *(const float4*)(mapb + off); asm volatile("" : "+v"(m.w)); top_insert_off<STRIDE>(t, l2_simple_pk(m, qxy, q.z), off); }
+    if (off < end) { float4 m = MSFL_LD(off); MSFL_PIN_W(m); top_insert_off<STRIDE>(t, l2_simple_pk(m, qxy, q.z), off); }
+#endif
   };
   // the same per-query row order as knn5_grid: centre, near sides (smaller gap first), far sides, near-near, mixed diagonals, far-far
   visit(v_y1 && v_z1, base0, q_y1 + q_z1);
@@ -734,9 +770,26 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   Top5 t;
   int n_cand = 0;
   const float bound = SEED ? knn5_seed_bound(is_edge ? map_c : map_s, out, q, max_sq_dist) : max_sq_dist;
+#if MSFL_KNN_KEY32
+  // the walk on truncated 32-bit keys first (Top6K); a lane it leaves ambiguous is searched again with the exact keys below
+  __shared__ int s_slot[kTopSlots * kAssocBlock];
+  Top6K tk;
+  top_init(tk, bound, s_slot + threadIdx.x);
+  if (is_edge) { const GridDesc gc = gcp[PAIRS ? b : 0]; knn5_grid_k32<kAssocBlock>(gc, map_c, cs_c, q, tk, n_cand, PAIRS ? cbase_c[b] : 0); }
+  else { const GridDesc gs = gsp[PAIRS ? b : 0]; knn5_grid_k32<kAssocBlock>(gs, map_s, cs_s, q, tk, n_cand, PAIRS ? cbase_s[b] : 0); }
+  const bool settled = top_settled(tk, max_sq_dist);
+  if (!settled) {
+    int n_again = 0;                   // the candidate counter reports the first walk
+    top5_init(t, bound);
+    if (is_edge) { const GridDesc gc = gcp[PAIRS ? b : 0]; knn5_grid(gc, map_c, cs_c + (PAIRS ? cbase_c[b] : 0), q, t, n_again); }
+    else { const GridDesc gs = gsp[PAIRS ? b : 0]; knn5_grid(gs, map_s, cs_s + (PAIRS ? cbase_s[b] : 0), q, t, n_again); }
+  }
+#else
+  const bool settled = false;
   top5_init(t, bound);
   if (is_edge) { const GridDesc gc = gcp[PAIRS ? b : 0]; knn5_grid(gc, map_c, cs_c + (PAIRS ? cbase_c[b] : 0), q, t, n_cand); }
   else { const GridDesc gs = gsp[PAIRS ? b : 0]; knn5_grid(gs, map_s, cs_s + (PAIRS ? cbase_s[b] : 0), q, t, n_cand); }
+#endif
   if (COUNT) {                                                  // one atomic per wavefront: sum over the lanes still here
     const unsigned long long act = __ballot(1);
     unsigned long long m = act;
@@ -744,6 +797,17 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
     while (m) { const int l = __ffsll((long long)m) - 1; tot += __shfl(n_cand, l); m &= m - 1; }
     if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(n_candidates, (unsigned long long)tot);
   }
+#if MSFL_KNN_KEY32
+  if (settled) {
+    if (top_found(tk)) {                                                              // :128 / :198: the 5th is below the gate
+      out[0] = top_pos<kAssocBlock>(tk, tk.k0); out[1] = top_pos<kAssocBlock>(tk, tk.k1); out[2] = top_pos<kAssocBlock>(tk, tk.k2);
+      out[3] = top_pos<kAssocBlock>(tk, tk.k3); out[4] = top_pos<kAssocBlock>(tk, tk.k4);   // nearest first, positions in the sorted map
+    } else {
+      out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1;
+    }
+    return;
+  }
+#endif
   if ((unsigned int)t.k4 != 0xffffffffu && (double)top5_d4(t) < (double)max_sq_dist) {      // :128 / :198
     // original map index -> position in the sorted map array (the fit kernel then gathers directly);
     // done here because this kernel runs at 8 waves/SIMD and hides the extra dependent load

@@ -439,6 +439,71 @@ def test_both_forms_of_the_5nn_search_agree_bit_for_bit(oracle, monkeypatch):
             h.close()
 
 
+def _lattice_job(rng):
+    """Lattice maps (exactly equal f32 distances, duplicated points) and queries on nodes, half and quarter pitches."""
+    g_ = np.arange(-6, 7, dtype=np.float32) * 0.5
+    X, Y = np.meshgrid(g_, g_, indexing="ij")
+    plane = np.stack([X.ravel(), Y.ravel(), np.full(X.size, -1.5, np.float32)], 1)
+    wall = np.stack([np.full(X.size, 3.5, np.float32), X.ravel(), Y.ravel() + 1.5], 1)
+    lat = np.concatenate([plane, wall, plane[::7]])
+    lat = np.concatenate([lat, np.zeros((len(lat), 1), np.float32)], 1).astype(np.float32)
+    lat = lat[rng.permutation(len(lat))]
+    line = np.stack([np.zeros(60, np.float32), np.zeros(60, np.float32), np.arange(60, dtype=np.float32) * 0.125], 1)
+    pole = np.concatenate([line, line[::5]]); pole = np.concatenate([pole, np.zeros((len(pole), 1), np.float32)], 1).astype(np.float32)
+    q = np.concatenate([plane[rng.integers(0, len(plane), 300)] + rng.choice([0.0, 0.25, 0.125], (300, 3)).astype(np.float32),
+                        wall[rng.integers(0, len(wall), 300)] + rng.choice([0.0, 0.25, -0.125], (300, 3)).astype(np.float32),
+                        np.array([[0, 0, -0.5], [0, 0, -0.5001], [0, 0, -0.54], [2.999, 0, -1.5], [0.5, 0.5, -0.5]], np.float32)])
+    surf = np.concatenate([q, np.zeros((len(q), 1), np.float32)], 1).astype(np.float32)
+    corner = np.concatenate([line[::3] + np.float32(0.05), np.zeros((20, 1), np.float32)], 1).astype(np.float32)
+    return pole, lat, corner, surf
+
+
+def test_truncated_key_walk_is_exact_on_ties_and_at_the_gate(oracle, monkeypatch):
+    """Round 4: the one-lane-per-query kernels walk with 32-bit keys (distance truncated to 29 bits | slot) and search a query
+    again with the exact (distance, index) keys when its final keys cannot decide the top-5 (two distances in one 2^-21 bucket,
+    a 5th distance in the gate's bucket).  On lattice maps nearly every query is such a tie: the mixed kernel (`lane`), the
+    per-kind kernel of batches of >= 65 536 features and the row-parallel form (exact keys only) must agree bit for bit, and
+    the accept sets must be the oracle's."""
+    from msf_loam_amd import capi
+    hs = {}
+    for form in ("lane", "rows"):
+        monkeypatch.setenv("MSFL_KNN_FORM", form)
+        hs[form] = capi.Handle(0)
+    monkeypatch.delenv("MSFL_KNN_FORM")
+    try:
+        rng = np.random.default_rng(41)
+        pole, lat, corner, surf = _lattice_job(rng)
+        poses = [np.array([0, 0, 0, 0, 0, 0, 1.0]), np.array([0.125, -0.25, 0.0, 0, 0, 0, 1.0]), np.array([0.25, 0.25, 0.5, 0, 0, 0, 1.0])]
+        for k in range(5):
+            p = np.r_[rng.normal(0, 0.05, 3), 0.5 * rng.normal(0, 0.004, 3), 1.0]; p[3:] /= np.linalg.norm(p[3:]); poses.append(p)
+        for h in hs.values():
+            h.set_map(pole, lat)
+        n_ok = 0
+        for pose in poses:
+            rec = {f: h.associate_scan2map(corner, surf, pose) for f, h in hs.items()}
+            assert np.array_equal(rec["lane"], rec["rows"])
+            corr = oracle.associate_scan2map(pole, lat, corner, surf, pose)
+            assert np.array_equal(np.any(rec["lane"][:, 3:] != 0, axis=1), corr["kind"] != 0)
+            n_ok += int((corr["kind"] != 0).sum())
+        assert n_ok > 1500
+        # the per-kind kernel: 120 copies of the job (75 000 features) in one batch against single calls through the rows form
+        B = 120
+        guesses = np.array([poses[i % len(poses)] for i in range(B)])
+        co = np.arange(B + 1, dtype=np.int32) * len(corner); so = np.arange(B + 1, dtype=np.int32) * len(surf)
+        assert co[-1] + so[-1] >= 65536
+        h = hs["lane"]
+        pb, sb, ib = h.match_scan2map_batch(np.tile(corner, (B, 1)), co, np.tile(surf, (B, 1)), so, guesses, want_info=True)
+        for i in range(len(poses)):
+            s1, p1, i1 = hs["rows"].match_scan2map(corner, surf, poses[i])
+            for j in range(i, B, len(poses)):
+                assert sb[j] == s1 and np.array_equal(pb[j], p1), (i, j)
+                assert list(ib[j].n_plane) == list(i1.n_plane) and list(ib[j].n_edge) == list(i1.n_edge)
+                assert list(ib[j].final_cost) == list(i1.final_cost)
+    finally:
+        for h in hs.values():
+            h.close()
+
+
 @pytest.mark.parametrize("form", ["lane", "split"])
 def test_seeded_second_pass_finds_the_same_neighbours(oracle, monkeypatch, form):
     """The second outer iteration's 5-NN search starts from the bound the first iteration's five neighbours give
