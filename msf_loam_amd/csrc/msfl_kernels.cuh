@@ -819,6 +819,12 @@ knn5_scan2map_kernel(BatchView bv, const double* __restrict__ poses, const int* 
   }
 }
 
+// a load the caller knows to be wave-uniform and of memory no thread of this kernel writes: emitted as a scalar load
+template <class V>
+__device__ __forceinline__ V uniform_load(const V* p) {
+  return *(const __attribute__((address_space(4))) V*)(unsigned long long)p;
+}
+
 // K4a for a whole large batch of the plain branch: blocks [0, edge_blocks) serve the corner features (corner map index), the rest
 // the surf features, so that a wavefront never holds both kinds and each body knows its map at compile time.
 template <bool EDGE, bool SEED>
@@ -828,13 +834,32 @@ __device__ __forceinline__ void knn5_one_kind(const BatchView& bv, const double*
   const int* off = EDGE ? bv.corner_off : bv.surf_off;
   const int f_i = off[0] + block * (int)blockDim.x + (int)threadIdx.x;
   if (f_i >= off[bv.n_scans]) return;
-  const int b = find_scan_wave(off, bv.n_scans, f_i);
-  const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
-  const int g = bv.rec_off[b] + (EDGE ? 0 : nc) + (f_i - off[b]);
+  // Nearly every wavefront lies inside ONE scan (two boundaries per scan in ~78 wavefronts): its scan number, offsets, status and
+  // pose are then read through the scalar unit — the kernel is bound by vector-memory instruction issue as much as by VALU issue
+  // (texture addresser ~80 % busy, profiles/r04b_knn_ta.md), and these were ten of its ~92 vector loads per wavefront.
+  const int b0 = __builtin_amdgcn_readfirstlane(find_scan(off, bv.n_scans, __builtin_amdgcn_readfirstlane(f_i)));
+  int b, nc, g, st; pose7 T;
+  if (__all(f_i < off[b0 + 1])) {
+    // loads through the constant address space (written by earlier kernels only), so that they stay scalar loads: with plain loads
+    // the optimiser merges the two branches into one set of per-lane loads again
+    b = b0;
+    nc = uniform_load(bv.corner_off + b0 + 1) - uniform_load(bv.corner_off + b0);
+    g = uniform_load(bv.rec_off + b0) + (EDGE ? 0 : nc) + (f_i - uniform_load(off + b0));
+    st = uniform_load(status + b0);
+    const double* pp = poses + 7 * b0;
+    T.t = mk3(uniform_load(pp), uniform_load(pp + 1), uniform_load(pp + 2));
+    T.q.x = uniform_load(pp + 3); T.q.y = uniform_load(pp + 4); T.q.z = uniform_load(pp + 5); T.q.w = uniform_load(pp + 6);
+  } else {
+    b = b0;
+    while (b + 1 < bv.n_scans && f_i >= off[b + 1]) b++;
+    nc = bv.corner_off[b + 1] - bv.corner_off[b];
+    g = bv.rec_off[b] + (EDGE ? 0 : nc) + (f_i - off[b]);
+    st = status[b];
+    T = load_pose(poses + 7 * b);
+  }
   int* out = nn + 5 * (size_t)g;
-  if (status[b] != 0) { out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1; return; }
+  if (st != 0) { out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1; return; }
   const float4 f = EDGE ? bv.corner[f_i] : bv.surf[f_i];
-  const pose7 T = load_pose(poses + 7 * b);
   const float3 q = transform_point_f32(T, f.x, f.y, f.z);                          // :123 / :193
   int n_cand = 0;
   const GridDesc gd = *gp;
