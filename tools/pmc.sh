@@ -1,4 +1,6 @@
 #!/bin/bash
+# (every pass under its own timeout: a counter set the box cannot collect must not take the whole call with it — the
+# TA_*_STALLED_* set hung rocprofv3 for 15 minutes in round 4)
 # Collect rocprofv3 PMC counters for the bench workload in separate passes (gpurun forbids mixing
 # --pmc with tracing domains other than --kernel-trace/--stats).  Run on the GPU box:
 #   bash tools/pmc.sh <tag> [bench args]
@@ -17,9 +19,10 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCC_HIT_sum TCC_MISS_sum" \
            "FETCH_SIZE" \
            "WRITE_SIZE" \
-           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"; do
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
+           "TA_TA_BUSY_sum TA_BUSY_avr TA_BUSY_max"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT -o pass$i -- $CMD > $OUT/pass$i.log 2>&1
+  timeout 240 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT -o pass$i -- $CMD > $OUT/pass$i.log 2>&1
 done
 python $ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 du -sh $OUT/* | sort -h | tail -5
