@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/${TAG}; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -4 > $O/gpu_tests.txt
+[ -n "${FUZZ:-}" ] && (MSFL_FUZZ_SEEDS=$FUZZ timeout 900 python -m pytest tests/test_gpu_extract.py tests/test_gpu_scan2map.py tests/test_gpu_scan2scan.py tests/test_grid_store.py tests/test_deskew.py -q -m gpu 2>&1 | tail -4 > $O/fuzz.txt)
 timeout 600 python bench.py --steps 200 --warmup 10 > $O/bench.json 2> $O/bench.err
 timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_driver_shape.json 2>> $O/bench.err
 timeout 400 bash tools/prof.sh ${TAG}/prof > $O/prof.txt 2>&1
@@ -14,7 +15,5 @@ for m in "" "--imu" "--reference-quirks" "--imu --reference-quirks"; do
   for mode in slam slam-pipelined; do timeout 200 python examples/replay_synthetic.py --scans 300 --mode $mode $m 2>/dev/null | tail -1; done
 done > $O/replay300.jsonl
 MSFL_SLAM_HOST_PROFILE=1 timeout 200 python examples/replay_synthetic.py --scans 300 --mode slam-pipelined > /dev/null 2> $O/slam_host_profile.txt
-for t in 0 1; do for mode in slam slam-pipelined; do MSFL_SLAM_THREADS=$t timeout 200 python examples/replay_synthetic.py --scans 300 --mode $mode 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('threads=$t', d['mode'], d['ms_per_scan_end_to_end'])"; done; done > $O/slam_threads.txt
 timeout 600 bash tools/slam_trace.sh 140 > $O/slam_trace.txt 2>&1; cp $R/gpurun_out/tl/*.md $O/ 2>/dev/null
-PMC_CMD="python $R/examples/replay_synthetic.py --scans 120 --mode slam" timeout 900 bash tools/pmc.sh ${TAG}/pmc_slam > $O/pmc_slam.txt 2>&1
 ls -la $O

@@ -16,7 +16,9 @@ for line in open(src):
         parts = line.split()
         if parts[0] in ("FETCH_SIZE", "WRITE_SIZE"):
             kernels[cur]["fetch_kb" if parts[0] == "FETCH_SIZE" else "write_kb"] = float(parts[2])
-        elif parts[0] in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
+        elif parts[0] in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+                          "SQ_INSTS_LDS", "SQ_INSTS_SALU", "TA_BUSY_avr", "TA_BUSY_max", "GRBM_GUI_ACTIVE", "TCP_TOTAL_CACHE_ACCESSES_sum",
+                          "TCP_TCC_READ_REQ_sum"):
             kernels[cur][parts[0].lower()] = float(parts[2])
 out = {"source": f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 "
                  "per MI355X_MICROARCH.md HBM note)", "kernels": {}}
