@@ -263,7 +263,7 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi, 
   HIPCHK(h, h->idx_count.reserve(((size_t)cap + 1) * sizeof(int)));
   if (h->idx_count.p != count_before) h->idx_count_zero = 0;
   HIPCHK(h, mi.cell_start.reserve(((size_t)cap + 1) * sizeof(int)));
-  HIPCHK(h, mi.sorted.reserve(((size_t)n + 4) * sizeof(float4))     /* + 4: the 5-NN walk requests the next two points ahead of a range's end (never used) */);
+  HIPCHK(h, mi.sorted.reserve(std::max<size_t>(1, (size_t)n) * sizeof(float4)));
   HIPCHK(h, mi.pos_of.reserve(std::max<size_t>(1, (size_t)n) * sizeof(int)));
   mi.cap_cells = cap;
   if (!mi.bbox.p) {                       // armed once; the build re-arms it after the last read

@@ -289,9 +289,6 @@ __device__ __forceinline__ void top5_insert(Top5& t, float d, int idx) {
 // is searched again with the exact 64-bit keys (Top5): two distances within 2^-21 relative of each other, ~1e-6 of the queries
 // on a scanned surface, every query on an exact lattice.  The 6th key's stored position may be stale (a candidate that tied
 // with it overwrote the slot without entering); the 6th is never output and can only leave the list.
-#ifndef MSFL_KNN_PREFETCH
-#define MSFL_KNN_PREFETCH 0         /* 1: the k32 walk requests the next candidate pair before working on the current one */
-#endif
 #ifndef MSFL_KNN_KEY32
 #define MSFL_KNN_KEY32 1            /* 0: the 64-bit (distance, index) keys of rounds 1-4a in every kernel (A/B) */
 #endif
@@ -469,15 +466,6 @@ __device__ __forceinline__ void top_insert_off(Top6K& t, float d, unsigned int o
   t.k0 = min(t.k0, x);
   t.bound = min(t.k4 | 7u, t.gate);
 }
-#ifndef MSFL_KNN_X3
-#define MSFL_KNN_X3 0               /* 1: let the k32 walk load 12 bytes per candidate (the index word is not used there) */
-#endif
-#if MSFL_KNN_X3
-typedef float msfl_f3 __attribute__((ext_vector_type(3)));      // 16-byte aligned, loaded as global_load_dwordx3
-#define MSFL_PIN_W(m)
-#else
-#define MSFL_PIN_W(m) asm volatile("" : "+v"(m.w))
-#endif
 template <int STRIDE>
 __device__ __forceinline__ void knn5_grid_k32(const GridDesc& g, const float4* __restrict__ sorted,
                                               const int* __restrict__ cell_start, float3 q, Top6K& t, int& n_cand,
@@ -528,37 +516,14 @@ __device__ __forceinline__ void knn5_grid_k32(const GridDesc& g, const float4* _
     n_cand += (int)(e - s);
     unsigned int off = s << 4;
     const unsigned int end = e << 4, last = end - 16u;      // last: offset of the range's last point (>= off)
-#if MSFL_KNN_PREFETCH
-    // software pipeline: the next pair is requested before the current one is worked on (four loads in flight; a lane's walk is a
-    // chain of load round trips and eight wavefronts per SIMD is all there is to hide them).  The pair after a range's end is
-    // requested and dropped: the sorted copy is allocated with four points of slack.  The odd tail is already in m0.
-    float4 m0 = *(const float4*)(mapb + off), m1 = *(const float4*)(mapb + off + 16u);
-#pragma unroll 2
-    while (off < last) {
-      const unsigned int nx = off + 32u;
-      float4 n0 = *(const float4*)(mapb + nx), n1 = *(const float4*)(mapb + nx + 16u);
-      MSFL_PIN_W(m0);           // keep the 16-byte loads (12-byte loads measured slower, rounds 1-2)
-      top_insert_off<STRIDE>(t, l2_simple_pk(m0, qxy, q.z), off);
-      MSFL_PIN_W(m1);
-      top_insert_off<STRIDE>(t, l2_simple_pk(m1, qxy, q.z), off + 16u);
-      m0 = n0; m1 = n1; off = nx;
-    }
-    if (off == last) { MSFL_PIN_W(m0); top_insert_off<STRIDE>(t, l2_simple_pk(m0, qxy, q.z), off); }
-#else
-#if MSFL_KNN_X3
-#define MSFL_LD(o) ([&]() { const msfl_f3 v = *(const msfl_f3*)(mapb + (o)); return make_float4(v.x, v.y, v.z, 0.0f); }())
-#else
-#define MSFL_LD(o) (*(const float4*)(mapb + (o)))
-#endif
     for (; off < last; off += 32u) {           // two loads in flight
-      float4 m0 = MSFL_LD(off), m1 = MSFL_LD(off + 16u);
-      MSFL_PIN_W(m0);           // keep the 16-byte loads (12-byte loads measured slower, rounds 1-2)
+      float4 m0 = *(const float4*)(mapb + off), m1 = *(const float4*)(mapb + off + 16u);
+      asm volatile("" : "+v"(m0.w));           // keep the 16-byte loads (12-byte loads: slower in rounds 1-2, no change in round 4b)
       top_insert_off<STRIDE>(t, l2_simple_pk(m0, qxy, q.z), off);
-      MSFL_PIN_W(m1);
+      asm volatile("" : "+v"(m1.w));
       top_insert_off<STRIDE>(t, l2_simple_pk(m1, qxy, q.z), off + 16u);
     }
-    if (off < end) { float4 m = MSFL_LD(off); MSFL_PIN_W(m); top_insert_off<STRIDE>(t, l2_simple_pk(m, qxy, q.z), off); }
-#endif
+    if (off < end) { float4 m = *(const float4*)(mapb + off); asm volatile("" : "+v"(m.w)); top_insert_off<STRIDE>(t, l2_simple_pk(m, qxy, q.z), off); }
   };
   // the same per-query row order as knn5_grid: centre, near sides (smaller gap first), far sides, near-near, mixed diagonals, far-far
   visit(v_y1 && v_z1, base0, q_y1 + q_z1);
