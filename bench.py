@@ -475,8 +475,8 @@ def main():
                          "vmem": vmem_roof(ASSOC_KERNEL_PREFIX) if (B == 1024 and args.map_points == 200000) else None,
                          "bound_note": "achieved / peak / frac are the HBM figures on ALGORITHMIC bytes (SURVEY.md 8d); `bound` names the roof the "
                                        "kernel is nearer to: its working set is L2-resident (traffic < algorithmic bytes) and its VALU issue "
-                                       "fraction (`valu.frac`) is the larger one; `vmem.ta_busy_frac` is the second resource at ~0.8: one "
-                                       "16-byte candidate load per lane is one texture-addresser request whatever the lane count",
+                                       "fraction (`valu.frac`) is the larger one; `vmem.ta_busy_frac` is the second resource at ~0.8: a "
+                                       "multi-dword load instruction costs the CU's texture addresser ~16 clocks whatever it fetches (profiles/r04b_vmem_rate.md)",
                          "kernels": (kernel_roofs({ASSOC_KERNEL_PREFIX: assoc_ms, "fit_scan2map": timing_all.ms_fit / max(timing_all.launches_fit, 1),
                                                    "lm_solve_kernel": solve_ms},
                                                   {ASSOC_KERNEL_PREFIX: alg_bytes_assoc, "fit_scan2map": F_total * (5 * 16 + 20 + 40),
