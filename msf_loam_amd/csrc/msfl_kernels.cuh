@@ -600,20 +600,34 @@ __device__ __forceinline__ FitOut edge_fit(const float4 (&nb)[5], double ratio) 
 }
 
 // mapping_scan_matcher.cc:199-222
+#ifndef MSFL_PLANE_ADJ
+#define MSFL_PLANE_ADJ 1            /* 0: the unpivoted-QR fast path of round 3 instead of the centred adjugate form (A/B) */
+#endif
 __device__ __forceinline__ FitOut plane_fit(const float4 (&nb)[5], double tol) {
   FitOut o; o.ok = false; o.C = mk3(0, 0, 0); o.N = mk3(0, 0, 0);
-  double A[5][3], b[5];
   d3 c = mk3(0, 0, 0);
 #pragma unroll
-  for (int j = 0; j < 5; j++) {
-    A[j][0] = (double)nb[j].x; A[j][1] = (double)nb[j].y; A[j][2] = (double)nb[j].z;
-    b[j] = -1.0;
-    c = c + mk3(A[j][0], A[j][1], A[j][2]);
-  }
+  for (int j = 0; j < 5; j++) c = c + mk3((double)nb[j].x, (double)nb[j].y, (double)nb[j].z);
   c = mk3(c.x / 5.0, c.y / 5.0, c.z / 5.0);
   bool well = false;
-  d3 x = MSFL_IEEE_DIV ? mk3(0, 0, 0) : lstsq5x3_fast(A, b, well);   // overwrites A, b
+  d3 x = mk3(0, 0, 0);
+#if MSFL_PLANE_ADJ
+  if (!MSFL_IEEE_DIV) {                            // direction of the least-squares solution only: all the fit uses
+    double q[5][3];                                // centred points (not kept across the fallback: the distance test re-forms them)
+#pragma unroll
+    for (int j = 0; j < 5; j++) { q[j][0] = (double)nb[j].x - c.x; q[j][1] = (double)nb[j].y - c.y; q[j][2] = (double)nb[j].z - c.z; }
+    x = plane_normal_centred(q, c, well);
+  }
+#else
+  {
+    double A[5][3], b[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { A[j][0] = (double)nb[j].x; A[j][1] = (double)nb[j].y; A[j][2] = (double)nb[j].z; b[j] = -1.0; }
+    if (!MSFL_IEEE_DIV) x = lstsq5x3_fast(A, b, well);             // overwrites A, b
+  }
+#endif
   if (!well) {                                     // ill-conditioned or rank-deficient: the reference's pivoted QR decides
+    double A[5][3], b[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) { A[j][0] = (double)nb[j].x; A[j][1] = (double)nb[j].y; A[j][2] = (double)nb[j].z; b[j] = -1.0; }
     x = lstsq5x3(A, b);

@@ -329,4 +329,43 @@ __device__ __forceinline__ d3 lstsq5x3_fast(double (&A)[5][3], double (&b)[5], b
   return mk3(y0, y1, y2);
 }
 
+// Direction of the least-squares solution of A x = -1 (rows of A: five points) WITHOUT forming x (round 4b).  With the centroid c
+// and q_j = p_j - c (sum q_j = 0):  sum_j (x.p_j + 1)^2 = 5 (x.c + 1)^2 + x^T Q x,  Q = sum_j q_j q_j^T, so
+//   (Q + 5 c c^T) x = -5 c   =>   x = -5 Q^-1 c / (1 + 5 c^T Q^-1 c)   (Sherman-Morrison; the factor is positive for SPD Q)
+// and the direction of x is that of -adj(Q) c: six cofactors and a 3 x 3 product, no square root, no division, no 5 x 3
+// factorisation.  It is also the limit for exactly coplanar points (Q singular: adj(Q) = l1 l2 n n^T).  The plane fit only uses
+// x / |x| (mapping_scan_matcher.cc:211), so this replaces the QR on the well-conditioned systems that are the rule; `ok` = false sends
+// the neighbourhood to lstsq5x3, the reference's pivoted QR, which alone decides rank-deficient and ill-conditioned ones:
+//  * the diagonal of the unpivoted Cholesky factor of A^T A = Q + 5 c c^T (= |r_kk| of the unpivoted QR of A, the criterion of the
+//    round-3 fast path) must span less than 1e5: min d_k > 1e-10 max d_k on its squares;
+//  * the cofactors and the product cancel by l1 / l2 (in-plane anisotropy) and |c| / |n.c| (grazing view): |adj(Q) c| must be above
+//    1e-6 of the magnitude of its terms, which bounds the formula's own rounding error by ~2e-10 relative (typically 1e-14).
+// `q` are the centred points.
+__device__ __forceinline__ d3 plane_normal_centred(const double (&q)[5][3], d3 c, bool& ok) {
+#pragma clang fp contract(fast)
+  double Q00 = 0, Q01 = 0, Q02 = 0, Q11 = 0, Q12 = 0, Q22 = 0;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    Q00 += q[j][0] * q[j][0]; Q01 += q[j][0] * q[j][1]; Q02 += q[j][0] * q[j][2];
+    Q11 += q[j][1] * q[j][1]; Q12 += q[j][1] * q[j][2]; Q22 += q[j][2] * q[j][2];
+  }
+  const double a00 = Q11 * Q22 - Q12 * Q12, a01 = Q02 * Q12 - Q01 * Q22, a02 = Q01 * Q12 - Q02 * Q11;
+  const double a11 = Q00 * Q22 - Q02 * Q02, a12 = Q01 * Q02 - Q00 * Q12, a22 = Q00 * Q11 - Q01 * Q01;
+  const d3 y = mk3(a00 * c.x + a01 * c.y + a02 * c.z, a01 * c.x + a11 * c.y + a12 * c.z, a02 * c.x + a12 * c.y + a22 * c.z);
+  // conditioning of A^T A = Q + 5 c c^T through its Cholesky diagonal (squares); reciprocals are good enough for a threshold
+  const double M00 = Q00 + 5.0 * c.x * c.x, M01 = Q01 + 5.0 * c.x * c.y, M02 = Q02 + 5.0 * c.x * c.z;
+  const double M11 = Q11 + 5.0 * c.y * c.y, M12 = Q12 + 5.0 * c.y * c.z, M22 = Q22 + 5.0 * c.z * c.z;
+  const double d0 = M00;
+  const double i0 = fast_rcp(d0);
+  const double d1 = M11 - M01 * M01 * i0;
+  const double l21 = M12 - M01 * M02 * i0;
+  const double d2 = M22 - M02 * M02 * i0 - l21 * l21 * fast_rcp(d1);
+  const double dmin = fmin(d0, fmin(d1, d2)), dmax = fmax(d0, fmax(d1, d2));
+  const double trq = Q00 + Q11 + Q22;
+  const double cm = fmax(fabs(c.x), fmax(fabs(c.y), fabs(c.z)));
+  const double ym = fmax(fabs(y.x), fmax(fabs(y.y), fabs(y.z)));
+  ok = dmin > 1e-10 * dmax && ym > 1e-6 * (trq * trq * cm);      // false for NaN too
+  return mk3(-y.x, -y.y, -y.z);
+}
+
 }  // namespace msfl
