@@ -237,7 +237,11 @@ def kernel_roofs(launch_ms, alg_bytes):
         if prefix in alg_bytes:
             row["algorithmic_bytes_per_launch"] = alg_bytes[prefix]
             row["algorithmic_GBps"] = alg_bytes[prefix] / (ms * 1e-3) / 1e9
-        fr = [(row["valu_frac"] or 0.0, "valu"), (row["fetched_frac_of_hbm_peak"] or 0.0, "memory (L2 misses)")]
+        vm = vmem_roof(prefix)
+        row["ta_busy_frac"] = None if vm is None else vm["ta_busy_frac"]
+        row["vmem_loads_per_wavefront"] = None if vm is None else vm["vmem_loads_per_wavefront"]
+        fr = [(row["valu_frac"] or 0.0, "valu"), (row["fetched_frac_of_hbm_peak"] or 0.0, "memory (L2 misses)"),
+              (row["ta_busy_frac"] or 0.0, "vector-memory instruction issue (texture addresser)")]
         row["nearer_roof"] = max(fr)[1]
         out[prefix] = row
     return out
