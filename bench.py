@@ -263,7 +263,7 @@ def host_buffer_rate(h, inp, B, reps=5):
     # the MEDIAN call: the host and its PCIe root are shared with the pod's other GPU slots, and one stalled copy among five calls
     # made a round-4 run report 80 k instead of 432 k registrations/s (gpurun_out/r04b/bench_driver_shape.json)
     dt = sorted(ts)[len(ts) // 2]
-    return B / dt, 1e3 * dt, int(c.nbytes + s.nbytes + g.nbytes), [1e3 * t for t in ts]
+    return B / dt, 1e3 * dt, int(c.nbytes + s.nbytes + g.nbytes), [1e3 * t for t in ts], B / (sum(ts) / len(ts))
 
 
 def main():
@@ -280,6 +280,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024, help="scans timed on the CPU oracle (0 disables; default: the whole batch)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: leave the per-kernel HIP events off during the timed steps (roofline.achieved is then 0)")
+    ap.add_argument("--steady-steps", type=int, default=200,
+                    help="steps of the steady-state companion figure (value_steady) run AFTER the timed region; 0 disables it")
+    ap.add_argument("--no-worlds", action="store_true", help="skip stages.worlds / config3_share / config4_share / pairs (round 5)")
+    ap.add_argument("--world-scans", type=int, default=256, help="scans per world in stages.worlds")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive leg (value_incl_h2d)")
     ap.add_argument("--no-stages", action="store_true", help="skip the `stages` leg (extraction, voxel filters, scan-to-scan, raw-scan pipeline, SLAM step)")
     ap.add_argument("--stage-slam-scans", type=int, default=100, help="scans of the SLAM-step replay in `stages` (0 disables it)")
@@ -409,6 +413,17 @@ def main():
     knn_first, knn_seeded = t_knn.knn_candidates, t_knn.knn_candidates_seeded
     knn_candidates = knn_first + knn_seeded
     h.set_timing(0)
+    # steady-state companion: the timed region above is `--steps` steps from wherever the clocks were after the
+    # warm-up (the driver's 20 steps sit on the ramp, profiles/r04_step_ramp.json); 200 more steps, same bracket, never `value`
+    steady_steps = args.steady_steps
+    elapsed_steady = None
+    if steady_steps > 0:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steady_steps):
+            step()
+        barrier()
+        elapsed_steady = time.perf_counter() - t0
     gc.enable()
     rank_ms = [1e3 * elapsed / args.steps]
     rccl_ranks = 1
@@ -419,6 +434,11 @@ def main():
         rank_ms = [1e3 * float(e.item()) / args.steps for e in every]
         elapsed = max(float(e.item()) for e in every)          # MAX over ranks
         rccl_ranks = dist.get_world_size()
+        if elapsed_steady is not None:
+            t = torch.tensor([elapsed_steady], dtype=torch.float64, device=dev if not shared_gpu else "cpu")
+            every = [torch.zeros_like(t) for _ in range(world_size)]
+            dist.all_gather(every, t)
+            elapsed_steady = max(float(e.item()) for e in every)
 
     poses_gpu = d_poses[:B].cpu().numpy()
     status_gpu = d_status[:B].cpu().numpy()
@@ -466,6 +486,8 @@ def main():
             "metric": "scan-to-map registrations/s", "value": value, "unit": "registrations/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "value_steady": None if elapsed_steady is None else total_scans * steady_steps / elapsed_steady,
+            "ms_per_step_steady": None if elapsed_steady is None else 1e3 * elapsed_steady / steady_steps, "steady_steps": steady_steps,
             "rccl_ranks": rccl_ranks, "ms_per_step_per_rank": rank_ms,
             "vs_baseline": None, "dtype": "f64 (f32 kNN distances)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: batch of %d VLP-16 scans (16x1800) vs %d-pt local map, "
@@ -516,9 +538,10 @@ def main():
             out["roofline"]["lm_instantiations"] = None
         out["value_incl_h2d"] = None               # N=1 only: the host-buffer call is a separate, untimed-for-`value` leg
         if world_size == 1 and not args.no_h2d:
-            v, ms, nbytes, ms_calls = host_buffer_rate(h, inp, B)
-            out["value_incl_h2d"] = {"value": v, "unit": "registrations/s", "ms_per_batch": ms, "ms_per_call": ms_calls, "host_bytes_in": nbytes,
-                                     "note": "median of the listed calls; same batch with features, guesses and results in pinned host memory (PCIe "
+            v, ms, nbytes, ms_calls, v_mean = host_buffer_rate(h, inp, B)
+            out["value_incl_h2d"] = {"value": v, "value_is": "median call", "value_mean_of_calls": v_mean, "unit": "registrations/s", "ms_per_batch": ms,
+                                     "ms_per_call": ms_calls, "host_bytes_in": nbytes,
+                                     "note": "`value` = the MEDIAN of the listed calls (rounds 1-3 reported the mean: `value_mean_of_calls`); same batch with features, guesses and results in pinned host memory (PCIe "
                                              "staging inside the call), map resident and indexed; never `value`"}
         out["cpu_baseline"] = None                 # timed on rank 0 at N=1 only (the other ranks would idle behind it)
         if args.cpu_sample > 0 and world_size == 1:
@@ -562,6 +585,10 @@ def main():
             t_st = time.perf_counter()
             out["stages"] = bench_stages.measure(inp["raw"], inp["world"], inp["map_corner"], inp["map_surf"], inp["truth"], inp["guesses"],
                                                  device=local_rank, slam_scans=args.stage_slam_scans, checker=checker)
+            if not args.no_worlds:
+                import bench_worlds
+                out["stages"]["worlds"] = bench_worlds.measure_worlds(device=local_rank, checker=checker, scans=args.world_scans)
+                out["stages"].update(bench_worlds.measure_shares(device=local_rank, checker=checker))
             out["stages"]["wall_s"] = time.perf_counter() - t_st
         print(json.dumps(out))
     h.close()

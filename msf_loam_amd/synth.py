@@ -71,12 +71,31 @@ def pose_error(a, b):
 # ---- world ------------------------------------------------------------------------------------
 
 class World:
-    def __init__(self, seed=SEED, n_poles=12, ground_half=80.0):
+    """kind = "room" (ground plane, 60 x 40 m room, poles), "outdoor" or "corridor" (round 5, `worlds.py`:
+    relief + buildings + trunks + volumetric canopy; a featureless 80 m corridor).  The room's streams of random numbers are
+    untouched by the other kinds: every seeded room case of rounds 1-4 is bit-identical."""
+
+    def __init__(self, seed=SEED, n_poles=12, ground_half=80.0, kind="room", **kw):
         rng = np.random.default_rng(seed)
+        self.kind = kind
         self.ground_half = float(ground_half)
         self.poles = np.stack([rng.uniform(-ROOM_HX + 2, ROOM_HX - 2, n_poles),
                                rng.uniform(-ROOM_HY + 2, ROOM_HY - 2, n_poles)], axis=1)
         self.seed = seed
+        self.geom = None
+        if kind == "outdoor":
+            from . import worlds
+            self.geom = worlds.Outdoor(seed + 11, **kw)
+        elif kind == "corridor":
+            from . import worlds
+            self.geom = worlds.Corridor(seed + 12, **kw)
+        elif kind != "room":
+            raise ValueError("unknown world kind %r" % (kind,))
+
+
+def world_poses(world, n, seed=SEED + 2):
+    """n sensor poses (scan -> world) suited to the world: `random_poses` in the room, the geometry's own elsewhere."""
+    return random_poses(n, seed) if world.geom is None else world.geom.random_poses(n, seed)
 
 
 def ground_half_for_target(total_points, n_poles=12, surf_spacing=0.4, corner_spacing=0.2):
@@ -90,6 +109,16 @@ def ground_half_for_target(total_points, n_poles=12, surf_spacing=0.4, corner_sp
 def make_map(world, seed=SEED + 1, corner_spacing=0.2, surf_spacing=0.4, jitter=0.005):
     """Local map clouds sampled from the world geometry: (corner (mc,4), surf (ms,4)) float32."""
     rng = np.random.default_rng(seed)
+    if world.geom is not None:
+        corner, surf = world.geom.make_map(rng, corner_spacing, surf_spacing, jitter)
+        surf = surf[rng.permutation(len(surf))]
+        corner = corner[rng.permutation(len(corner))]
+        out = []
+        for a in (corner, surf):
+            p = np.zeros((len(a), 4), np.float32)
+            p[:, :3] = a.astype(np.float32)
+            out.append(p)
+        return out[0], out[1]
     g = world.ground_half
     ax = np.arange(-g, g + 1e-9, surf_spacing)
     gx, gy = np.meshgrid(ax, ax, indexing="ij")
@@ -144,10 +173,13 @@ def beam_dirs(n_beams=16, n_az=1800, elev_lo=-15.0, elev_hi=15.0):
     return d.reshape(-1, 3), ring
 
 
-def raycast(world, R, t, dirs_local):
-    """Range and hit kind (0 ground, 1 wall, 2 pole, -1 miss) of rays from t along R @ d."""
+def raycast(world, R, t, dirs_local, rng=None):
+    """Range and hit kind (0 ground, 1 wall, 2 pole, 3 volume, -1 miss) of rays from t along R @ d.  `rng`: only the
+    volumetric returns of the outdoor world draw from it."""
     d = dirs_local @ R.T
     o = np.asarray(t, dtype=np.float64)
+    if world.geom is not None:
+        return world.geom.raycast(o, d, rng if rng is not None else np.random.default_rng(0))
     n = len(d)
     best = np.full(n, np.inf)
     kind = np.full(n, -1, np.int8)
@@ -187,7 +219,7 @@ def make_scan(world, pose, seed, n_beams=16, n_az=1800, elev=(-15.0, 15.0), nois
     rng = np.random.default_rng(seed)
     dirs, ring = beam_dirs(n_beams, n_az, elev[0], elev[1])
     R = quat_to_matrix(np.asarray(pose[3:], dtype=np.float64))
-    rng_m, kind = raycast(world, R, pose[:3], dirs)
+    rng_m, kind = raycast(world, R, pose[:3], dirs, rng)
     rng_m = rng_m + rng.normal(0, noise, rng_m.shape)
     ok = np.isfinite(rng_m) & (rng_m >= 0.3) & (rng_m <= 100.0) & (kind >= 0)
     p = dirs[ok] * rng_m[ok, None]

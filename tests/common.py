@@ -33,3 +33,53 @@ def features_from_oracle(orc, pts, ring):
     corner = orc.voxel_grid(f["full"][f["less_sharp"]], 0.2)
     surf = orc.voxel_grid(f["full"][f["less_flat"]], 0.4)
     return f, corner, surf
+
+
+# ---- round 5: the other two synthetic worlds (msf_loam_amd/worlds.py) -------------------------------------------------
+
+@functools.lru_cache(maxsize=None)
+def other_world(kind):
+    """(world, map_corner, map_surf) of the `outdoor` / `corridor` world (`room`: small_world())."""
+    if kind == "room":
+        return small_world()
+    w = synth.World(kind=kind)
+    mc, ms = synth.make_map(w)
+    return w, mc, ms
+
+
+@functools.lru_cache(maxsize=None)
+def other_scans(kind, n, seed=synth.SEED + 2):
+    """n raw sensor clouds of that world + true poses + perturbed guesses."""
+    if kind == "room":
+        return scans(n)
+    w, _, _ = other_world(kind)
+    poses = synth.world_poses(w, n, seed)
+    rng = np.random.default_rng(seed + 1000)
+    out = []
+    for i in range(n):
+        pts, ring = synth.make_scan(w, poses[i], seed + 10 + i)
+        out.append((pts, ring, poses[i], synth.perturb_pose(poses[i], rng)))
+    return out
+
+
+def world_drive(kind, n):
+    """A drive through the world for the sequential replay (~0.4 m and a degree or two per scan): along the x = 0 street of the
+    outdoor world (relief followed, gentle weaving), down the corridor's axis."""
+    w, _, _ = other_world(kind)
+    poses = []
+    for k in range(n):
+        a = k / max(n - 1, 1)
+        if kind == "outdoor":
+            y = -25.0 + 0.4 * k
+            x = 1.2 * np.sin(0.11 * k)
+            yaw = np.pi / 2 - np.arctan(1.2 * 0.11 * np.cos(0.11 * k) / 0.4) * 0.5
+            z = float(w.geom.ground(x, y)) + 1.8 + 0.02 * np.sin(0.5 * k)
+            poses.append(np.r_[x, y, z, synth.quat_from_euler(0.015 * np.sin(0.3 * k), 0.01 * np.cos(0.2 * k), yaw)])
+        elif kind == "corridor":
+            x = -20.0 + 0.4 * k
+            y = 0.3 * np.sin(0.15 * k)
+            poses.append(np.r_[x, y, 1.5 + 0.02 * np.sin(0.4 * k), synth.quat_from_euler(0.01 * np.sin(0.3 * k), 0.01 * np.cos(0.25 * k), 0.05 * np.sin(0.2 * k))])
+        else:
+            raise ValueError(kind)
+        del a
+    return np.array(poses)

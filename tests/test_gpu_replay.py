@@ -302,3 +302,33 @@ def test_two_handles_on_two_threads(oracle):
         assert all(np.array_equal(a, b) for a, b in zip(out_map[rep], ref_map))
         assert all(np.array_equal(a, b) for a, b in zip(out_odo[rep], ref_odo))
     mapper.close(); odom.close()
+
+
+@pytest.mark.parametrize("kind", ["outdoor", "corridor"])
+def test_device_resident_slam_step_in_the_other_worlds(oracle, kind):
+    """Round 5: BASELINE configs[2]'s step away from the room.  A 100-scan drive down the outdoor world's
+    street (relief, building faces, trunks, volumetric canopy: the map stores fill with leaf-dense cells) and down the 80 m
+    corridor (LOAM's classic failure: nothing constrains the motion along the axis, the estimate stays behind the truth) —
+    what is tested is that the device-resident chain reproduces the oracle-driven loop pose by pose (<= 1e-6 m / 1e-6 rad),
+    failure included, with the same final map stores (laser_odometry.cc:69-95, laser_mapping.cc:138-338)."""
+    from tests import common
+    n = 100
+    world, _, _ = common.other_world(kind)
+    truth = common.world_drive(kind, n)
+    scans = [synth.make_scan(world, truth[k], synth.SEED + 7000 + k) for k in range(n)]
+    maps_o, maps_g = {}, {}
+    est_o, _ = rp.run(OracleBackendRigid3d(oracle), world, truth, scans=scans, maps_out=maps_o)
+    est_g, recs, _ = rp.run_slam(world, truth, pipelined=True, scans=scans, maps_out=maps_g)
+    d = np.array([synth.pose_error(a, b) for a, b in zip(est_g, est_o)])
+    assert d[:, 0].max() < 1e-6 and d[:, 1].max() < 1e-6, (kind, d.max(axis=0), int(d[:, 0].argmax()))
+    assert all(r.status_extract == 0 for r in recs) and sum(1 for r in recs if r.status_mapping != 0) <= 2
+    for k in ("corner", "surf"):
+        assert maps_g[k].shape == maps_o[k].shape, (k, maps_g[k].shape, maps_o[k].shape)
+        assert np.abs(maps_g[k] - maps_o[k]).max() < 1e-4
+    assert abs(rp.ate(est_g, truth) - rp.ate(est_o, truth)) < 1e-6
+    if kind == "outdoor":
+        assert rp.ate(est_g, truth) < 0.6                      # LOAM tracks the street (drift ~1.5 % of the 40 m driven)
+    else:
+        assert rp.ate(est_g, truth) > 5.0                      # and loses the corridor's axis, like the CPU loop does
+    est_s, _, _ = rp.run_slam(world, truth[:40], pipelined=False, scans=scans[:40])
+    assert np.array_equal(est_s, est_g[:40])

@@ -578,3 +578,68 @@ def test_seeded_second_pass_finds_the_same_neighbours(oracle, monkeypatch, form)
                 assert list(res[0][2].n_plane) == list(res[1][2].n_plane) and list(res[0][2].final_cost) == list(res[1][2].final_cost)
     finally:
         h0.close(); h1.close()
+
+
+@pytest.mark.parametrize("kind", ["outdoor", "corridor"])
+def test_other_worlds_follow_the_oracle(gpu, oracle, kind):
+    """Round 5: the registration off its home field.  `outdoor`: 680 k map points, a quarter of the occupied
+    cells leaf-dense volumes (hundreds of candidates in a query's 27 cells; five neighbours that fit no line / plane and are
+    rejected by the eigenvalue ratio / the 0.2 m plane test); `corridor`: the along-axis direction nearly unobservable, trust-region
+    steps rejected.  Accept sets, accepted counts and LM iteration / success counts equal the oracle's, records <= 1e-9, poses <= 1e-7;
+    the batch call and both 5-NN forms give the single call's bits (mapping_scan_matcher.cc:109-259)."""
+    from msf_loam_amd import capi
+    _, mc, ms = common.other_world(kind)
+    gpu.set_map(mc, ms)
+    cs, ss, co, so, guesses, singles = [], [], [0], [0], [], []
+    n_rejected_fits, n_rejected_steps = 0, 0
+    for pts, ring, truth, guess in common.other_scans(kind, 4):
+        _, corner, surf = common.features_from_oracle(oracle, pts, ring)
+        rec_g = gpu.associate_scan2map(corner, surf, guess)
+        rec_o, corr = _oracle_records(oracle, mc, ms, corner, surf, guess)
+        acc_o = corr["kind"] != 0
+        assert np.array_equal(np.any(rec_g[:, 3:] != 0, axis=1), acc_o), "accepted-correspondence sets differ"
+        n_rejected_fits += int((~acc_o).sum())
+        n_dot = np.abs(np.sum(rec_g[acc_o, 3:] * rec_o[acc_o, 3:], axis=1))
+        assert np.all(np.abs(n_dot - 1) < 1e-9)
+        pl = acc_o.copy(); pl[:len(corner)] = False
+        assert np.abs(rec_g[pl, :3] - rec_o[pl, :3]).max() < 1e-9
+        rc, pose_o, info_o = oracle.match_scan2map(mc, ms, corner, surf, guess)
+        s, pose_g, info_g = gpu.match_scan2map(corner, surf, guess)
+        assert s == 0 and rc == 0
+        assert list(info_g.n_edge) == list(info_o.n_edge) and list(info_g.n_plane) == list(info_o.n_plane)
+        assert list(info_g.lm_iterations) == list(info_o.lm_iterations) and list(info_g.lm_successful) == list(info_o.lm_successful)
+        n_rejected_steps += sum(info_o.lm_iterations) - sum(info_o.lm_successful)
+        dt, dr = synth.pose_error(pose_g, pose_o)
+        assert dt < TIGHT and dr < TIGHT, (kind, dt, dr)
+        cs.append(corner); ss.append(surf); co.append(co[-1] + len(corner)); so.append(so[-1] + len(surf)); guesses.append(guess); singles.append(pose_g)
+    assert n_rejected_fits > 500                       # the worlds do produce neighbourhoods that are neither line nor plane
+    if kind == "corridor":
+        assert n_rejected_steps > 0
+    poses, st, _ = gpu.match_scan2map_batch(np.concatenate(cs), co, np.concatenate(ss), so, guesses)
+    assert np.all(st == 0) and all(np.array_equal(poses[b], singles[b]) for b in range(4))
+    # 16 copies of the batch go through the per-kind kernel of batches of >= 65 536 features (outdoor only reaches that)
+    reps = 16
+    C, S = np.concatenate(cs * reps), np.concatenate(ss * reps)
+    co2 = np.cumsum([0] + [len(c) for c in cs * reps]).astype(np.int32); so2 = np.cumsum([0] + [len(x) for x in ss * reps]).astype(np.int32)
+    poses2, st2, _ = gpu.match_scan2map_batch(C, co2, S, so2, guesses * reps)
+    assert np.all(st2 == 0) and all(np.array_equal(poses2[b], singles[b % 4]) for b in range(4 * reps))
+    if kind == "outdoor":
+        assert co2[-1] + so2[-1] >= 65536
+    # the row-parallel latency form of the search on the same map
+    import os as _os
+    old = _os.environ.get("MSFL_KNN_FORM")
+    _os.environ["MSFL_KNN_FORM"] = "rows"
+    try:
+        h = capi.Handle(0)
+    finally:
+        if old is None:
+            del _os.environ["MSFL_KNN_FORM"]
+        else:
+            _os.environ["MSFL_KNN_FORM"] = old
+    try:
+        h.set_map(mc, ms)
+        for b in range(2):
+            s, p, _ = h.match_scan2map(cs[b], ss[b], guesses[b])
+            assert s == 0 and np.array_equal(p, singles[b])
+    finally:
+        h.close()
