@@ -9,9 +9,10 @@
 //   msfl::Rigid3d                               <- src/common/rigid_transform.h:36-128
 //   msfl::TimestampedPointCloud<T>              <- src/common/timestamped_pointcloud.h:11-42
 //   msfl::PointXYZI / PointXYZIRT               <- pcl::PointXYZI / src/common/common.h:44-62
-// The point types here are packed PODs; INTEGRATION.md shows the 10-line conversion from the
-// reference's 32-byte PCL points.  Everything heavy runs in libmsfl_hip.so on the GPU; these
-// classes only marshal.  A matcher object owns one msfl_handle (one HIP stream), exactly as the
+// The point types here are packed PODs.  The marshalling itself lives in msfl/reference_adapter.hpp as templates over the
+// caller's cloud / rigid / vector types: these classes are its instantiation with the PODs below, the reference tree
+// instantiates the SAME functions with its PCL / Eigen types.  Everything heavy runs in libmsfl_hip.so on the
+// GPU; these classes only marshal.  A matcher object owns one msfl_handle (one HIP stream), exactly as the
 // reference owns one matcher per thread (laser_odometry.h:29, laser_mapping.h:65).
 #pragma once
 #include <array>
@@ -24,6 +25,7 @@
 #include <vector>
 
 #include "../msfl_c_api.h"
+#include "reference_adapter.hpp"
 
 namespace msfl {
 
@@ -131,19 +133,9 @@ struct RobotState {
 };
 
 namespace detail {
-inline void Check(msfl_status s, msfl_handle* h, const char* what) {
-  // the reference aborts through glog CHECK on invariant violations; here: an exception
-  if (s != MSFL_OK) throw std::runtime_error(std::string(what) + ": " + msfl_status_string(s) + " " + (h ? msfl_last_error(h) : ""));
-}
-inline std::vector<msfl_point> Pack(const PointCloud<PointXYZI>& c) {
-  std::vector<msfl_point> o(c.size());
-  for (std::size_t i = 0; i < c.size(); ++i) o[i] = msfl_point{c[i].x, c[i].y, c[i].z, c[i].intensity};
-  return o;
-}
-inline void Pack(const PointCloud<PointXYZIRT>& c, std::vector<msfl_point>* p, std::vector<std::uint16_t>* r) {
-  p->resize(c.size()); r->resize(c.size());
-  for (std::size_t i = 0; i < c.size(); ++i) { (*p)[i] = msfl_point{c[i].x, c[i].y, c[i].z, c[i].intensity}; (*r)[i] = c[i].ring; }
-}
+using adapter::Check;
+inline std::vector<msfl_point> Pack(const PointCloud<PointXYZI>& c) { return adapter::Pack(c); }
+inline void Pack(const PointCloud<PointXYZIRT>& c, std::vector<msfl_point>* p, std::vector<std::uint16_t>* r) { adapter::PackWithRing(c, p, r); }
 }  // namespace detail
 
 // scan_matcher.h:13-22.  RefineByRejectOutliersWithThreshold is a no-op in the reference
@@ -172,18 +164,7 @@ class OdometryScanMatcher : public ScanMatcher {
   virtual bool MatchScan2Scan(const TimestampedPointCloud<PointTypeOriginal>& scan_last,
                               const TimestampedPointCloud<PointTypeOriginal>& scan_curr,
                               Rigid3d* pose_estimate_curr2last) {
-    std::vector<msfl_point> p[4]; std::vector<std::uint16_t> r[4];
-    detail::Pack(*scan_last.cloud_corner_less_sharp, &p[0], &r[0]);
-    detail::Pack(*scan_last.cloud_surf_less_flat, &p[1], &r[1]);
-    detail::Pack(*scan_curr.cloud_corner_sharp, &p[2], &r[2]);
-    detail::Pack(*scan_curr.cloud_surf_flat, &p[3], &r[3]);
-    msfl_ring_cloud c[4];
-    for (int k = 0; k < 4; ++k) c[k] = msfl_ring_cloud{p[k].data(), r[k].data(), static_cast<int>(p[k].size())};
-    auto v = pose_estimate_curr2last->ToVector7();
-    const msfl_status s = msfl_match_scan2scan(h_, &c[0], &c[1], &c[2], &c[3], v.data(), &info_, MSFL_MEM_HOST);
-    if (s != MSFL_OK && s != MSFL_TOO_FEW_CORRESPONDENCES) detail::Check(s, h_, "msfl_match_scan2scan");
-    *pose_estimate_curr2last = Rigid3d(v);
-    return s == MSFL_OK;
+    return adapter::MatchScan2Scan(h_, scan_last, scan_curr, pose_estimate_curr2last, &info_);
   }
 };
 
@@ -262,28 +243,7 @@ class MappingScanMatcher : public ScanMatcher {
                              "branch from the IMU-only solve of prev_state (mapping_scan_matcher.cc:28-59), not from the incoming pose");
     if (!pose_estimate_map_scan2world || !velocity) throw std::invalid_argument("MatchScan2Map: null pose / velocity");
     imu_presolve_(prev_state, pose_estimate_map_scan2world, velocity);  // .cc:58-59
-    if (!preintegration || preintegration->sum_dt_buf_.size() < 2 ||
-        preintegration->delta_q_buf_.size() != preintegration->sum_dt_buf_.size() ||
-        preintegration->delta_p_buf_.size() != preintegration->sum_dt_buf_.size())
-      throw std::invalid_argument("MatchScan2Map: is_initialized needs a pre-integration with >= 2 samples");
-    msfl_preintegration pre;
-    pre.sum_dt = preintegration->sum_dt_buf_.data();
-    pre.delta_q = preintegration->delta_q_buf_[0].data();
-    pre.delta_p = preintegration->delta_p_buf_[0].data();
-    pre.n = static_cast<int>(preintegration->sum_dt_buf_.size());
-    DeskewInputs d;
-    d.gravity_vector = gravity_vector;
-    const std::vector<msfl_point> c = detail::Pack(*scan_curr.cloud_corner_less_sharp);
-    const std::vector<msfl_point> s = detail::Pack(*scan_curr.cloud_surf_less_flat);
-    d.corner_delta_q.resize(c.size()); d.corner_delta_p.resize(c.size());
-    d.surf_delta_q.resize(s.size()); d.surf_delta_p.resize(s.size());
-    if (!c.empty())
-      detail::Check(msfl_delta_qp(h_, &pre, c.data(), static_cast<int>(c.size()), d.corner_delta_q[0].data(), d.corner_delta_p[0].data(),
-                                  MSFL_MEM_HOST), h_, "msfl_delta_qp (corner)");
-    if (!s.empty())
-      detail::Check(msfl_delta_qp(h_, &pre, s.data(), static_cast<int>(s.size()), d.surf_delta_q[0].data(), d.surf_delta_p[0].data(),
-                                  MSFL_MEM_HOST), h_, "msfl_delta_qp (surf)");
-    return MatchScan2Map(cloud_map, scan_curr, true, &d, pose_estimate_map_scan2world, velocity);
+    return adapter::MatchScan2Map(h_, cloud_map, scan_curr, true, preintegration, gravity_vector, pose_estimate_map_scan2world, velocity, &info_);
   }
 
  private:
@@ -303,26 +263,9 @@ class ScanRegistration {
   ScanRegistration& operator=(const ScanRegistration&) = delete;
 
   TimestampedPointCloud<PointTypeOriginal> Extract(const PointCloud<PointTypeOriginal>& laser_cloud_in, double stamp) {
-    std::vector<msfl_point> p; std::vector<std::uint16_t> r;
-    detail::Pack(laser_cloud_in, &p, &r);
-    const std::size_t n = p.size();
-    std::vector<msfl_point> full(n); std::vector<std::uint16_t> ring(n); std::vector<float> curv(n); std::vector<std::uint8_t> label(n);
-    std::vector<int> idx[4];
-    for (auto& v : idx) v.resize(n);
-    msfl_features f{};
-    f.full_pts = full.data(); f.full_ring = ring.data(); f.curvature = curv.data(); f.label = label.data();
-    f.sharp_idx = idx[0].data(); f.less_sharp_idx = idx[1].data(); f.flat_idx = idx[2].data(); f.less_flat_idx = idx[3].data();
-    const auto ext = lidar2imu_.ToVector7();
-    detail::Check(msfl_extract_features(h_, p.data(), r.data(), static_cast<int>(n), ext.data(), &f, MSFL_MEM_HOST), h_,
-                  "msfl_extract_features");
     TimestampedPointCloud<PointTypeOriginal> scan;
     scan.time = stamp;
-    auto at = [&](int i) { return PointXYZIRT{full[i].x, full[i].y, full[i].z, full[i].t, ring[i], full[i].t}; };   // time == intensity, :152-153
-    for (int i = 0; i < f.n_full; ++i) scan.cloud_full_res->push_back(at(i));
-    for (int k = 0; k < f.n_sharp; ++k) scan.cloud_corner_sharp->push_back(at(idx[0][k]));
-    for (int k = 0; k < f.n_less_sharp; ++k) scan.cloud_corner_less_sharp->push_back(at(idx[1][k]));
-    for (int k = 0; k < f.n_flat; ++k) scan.cloud_surf_flat->push_back(at(idx[2][k]));
-    for (int k = 0; k < f.n_less_flat; ++k) scan.cloud_surf_less_flat->push_back(at(idx[3][k]));
+    adapter::Extract(h_, laser_cloud_in, lidar2imu_, &scan);
     return scan;
   }
 
@@ -346,24 +289,13 @@ class HybridGrid {
 
   std::shared_ptr<PointCloud<PointType>> GetSurroundedCloud(const std::shared_ptr<const PointCloud<PointType>>& scan,
                                                             const Rigid3d& pose) {
-    const std::vector<msfl_point> in = detail::Pack(*scan);
-    int n_pts = 0, n_cells = 0;
-    detail::Check(msfl_grid_size(g_, &n_pts, &n_cells), h_, "msfl_grid_size");
-    std::vector<msfl_point> out(static_cast<std::size_t>(n_pts > 0 ? n_pts : 1));
-    int n_out = 0;
-    const auto v = pose.ToVector7();
-    detail::Check(msfl_grid_get_surrounded(g_, in.data(), static_cast<int>(in.size()), v.data(), out.data(), n_pts, &n_out,
-                                           MSFL_MEM_HOST), h_, "msfl_grid_get_surrounded");
     auto cloud = std::make_shared<PointCloud<PointType>>();
-    cloud->points.reserve(static_cast<std::size_t>(n_out));
-    for (int i = 0; i < n_out; ++i) cloud->push_back({out[i].x, out[i].y, out[i].z, out[i].t});
+    adapter::GetSurroundedCloud(h_, g_, *scan, pose, cloud.get());
     return cloud;
   }
 
   void InsertScan(const std::shared_ptr<PointCloud<PointType>>& scan) {
-    if (scan->empty()) return;                                        // hybrid_grid.cc:504
-    const std::vector<msfl_point> in = detail::Pack(*scan);
-    detail::Check(msfl_grid_insert_scan(g_, in.data(), static_cast<int>(in.size()), MSFL_MEM_HOST), h_, "msfl_grid_insert_scan");
+    adapter::InsertScan(h_, g_, *scan);
   }
 
  private:

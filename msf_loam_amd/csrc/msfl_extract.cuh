@@ -933,7 +933,14 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   unsigned short* const s_ord1 = kGlobal ? g_ord + (size_t)blockIdx.x * 2 * kVoxMaxRuns + kVoxMaxRuns : s_ord_lds[1];
   auto s_ord = [&](int which) __attribute__((always_inline)) { return which ? s_ord1 : s_ord0; };
   __shared__ unsigned short s_hist[kVoxWaves][256];
-  __shared__ int s_wcount[kVoxWaves];
+  // Round 5: the run slots are ONE pool per cloud, handed out chunk by chunk (a chunk = 64 consecutive points of a wavefront's slice:
+  // one LDS atomic per chunk), instead of kVoxRunsPerWave slots per wavefront.  A list whose runs crowd into a few slices (the
+  // upper rings of an outdoor scan are canopy: nearly every point its own voxel, 900-1 000 runs in a 1 400-point slice while the
+  // whole list has 8-10 k) no longer overflows a 768-slot slice and sends the batch to the device-wide form.  The chunk table
+  // (first slot, runs) restores the arrival order for the sort: chunks in (wavefront, position) order, slots ascending inside.
+  constexpr int kMaxChunks = kVoxWaves * 64;                  // <= 65 535 (4 096) points over 16 (4) slices of whole chunks
+  __shared__ unsigned short s_cbase[kMaxChunks], s_ccnt[kMaxChunks];
+  __shared__ int s_alloc;
   __shared__ int s_bb[6];
   __shared__ int s_flag, s_total, s_wsum[kVoxWaves];
   const int b = blockIdx.x;
@@ -943,13 +950,14 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   // the small instantiation runs first and ESCALATES (flag 5) what it cannot hold; the large one then only serves those
   constexpr bool kSmall = kVoxWaves < 16;
   if (only_escalated && flags[b] != (only_escalated == 2 ? 4 : 5)) return;
-  if (tid == 0) { s_flag = 0; for (int a = 0; a < 3; a++) { s_bb[a] = INT32_MAX; s_bb[3 + a] = INT32_MIN; } }
+  if (tid == 0) { s_flag = 0; s_alloc = 0; for (int a = 0; a < 3; a++) { s_bb[a] = INT32_MAX; s_bb[3 + a] = INT32_MIN; } }
+  for (int c = tid; c < kMaxChunks; c += kThreads) s_ccnt[c] = 0;
   __syncthreads();
   if (n > (kSmall ? kVoxSmallPoints : kVoxMaxPoints)) { if (tid == 0) { flags[b] = kSmall ? 5 : 4; m_out[b] = 0; } return; }
   // ---- phase 1 ----
   const int seg = ((n + kVoxWaves - 1) / kVoxWaves + 63) & ~63;       // points per wavefront, whole chunks
   const int k0 = wave * seg, k1 = min(k0 + seg, n);
-  int n_runs = 0;                                                      // of this wavefront (uniform)
+  const int chunk0 = wave * (seg >> 6);                                // this slice's first entry of the chunk table
   int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
   int my_flag = 0;
   constexpr int kU = 4;                                                // chunks whose loads are in flight together
@@ -993,15 +1001,23 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
       const unsigned long long heads = __ballot(head), live = __ballot(valid);
       int len = 0;                                                       // of the run this lane opens
       int slot = 0;
+      const int n_heads = __popcll(heads);
+      int cbase = 0;
+      if (lane == 0) {
+        cbase = atomicAdd(&s_alloc, n_heads);                            // this chunk's slots in the cloud's pool
+        const int ci = chunk0 + ((base - k0) >> 6);
+        s_cbase[ci] = (unsigned short)min(cbase, 65535); s_ccnt[ci] = (unsigned short)n_heads;
+      }
+      cbase = __builtin_amdgcn_readfirstlane(cbase);
       if (head) {
         const unsigned long long above = heads & ~((2ull << lane) - 1ull);             // heads in higher lanes
         const int end = above ? __ffsll((long long)above) - 1 : __popcll(live);
-        slot = n_runs + __popcll(heads & ((1ull << lane) - 1ull));
+        slot = cbase + __popcll(heads & ((1ull << lane) - 1ull));
         len = end - lane;
-        if (slot < kVoxRunsPerWave)
-          s_run[wave * kVoxRunsPerWave + slot] = ((unsigned long long)(unsigned)(c0 + 8192) << 50) | ((unsigned long long)(unsigned)(c1 + 8192) << 36) |
-                                                 ((unsigned long long)(unsigned)(c2 + 8192) << 22) | ((unsigned long long)(unsigned)k << 6) |
-                                                 (unsigned long long)(len - 1);
+        if (slot < kVoxMaxRuns)
+          s_run[slot] = ((unsigned long long)(unsigned)(c0 + 8192) << 50) | ((unsigned long long)(unsigned)(c1 + 8192) << 36) |
+                        ((unsigned long long)(unsigned)(c2 + 8192) << 22) | ((unsigned long long)(unsigned)k << 6) |
+                        (unsigned long long)(len - 1);
       }
       // The run's points summed in arrival order while they are in registers: head lane h adds the values of lanes
       // h + 1, h + 2, ... one per step, every lane's value moving one lane down per step on the DPP network
@@ -1018,24 +1034,22 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
           const bool on = e < len;
           sx += on ? vx : 0.f; sy += on ? vy : 0.f; sz += on ? vz : 0.f; st += on ? vt : 0.f;
         }
-        if (head && slot < kVoxRunsPerWave) run_sums[v.off[b] + k0 + slot] = make_float4(sx, sy, sz, st);     // a slice has no more runs than points
+        if (head && slot < kVoxMaxRuns) run_sums[v.off[b] + slot] = make_float4(sx, sy, sz, st);     // a cloud has no more runs than points
       }
-      n_runs += __popcll(heads);
     }
   }
-  if (n_runs > kVoxRunsPerWave) my_flag = max(my_flag, kSmall ? 5 : 4);
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mn[a] = min(mn[a], __shfl_xor(mn[a], o)); mx[a] = max(mx[a], __shfl_xor(mx[a], o)); }
   if (lane == 0) {
-    s_wcount[wave] = min(n_runs, kVoxRunsPerWave);
     for (int a = 0; a < 3; a++) { atomicMin(&s_bb[a], mn[a]); atomicMax(&s_bb[3 + a], mx[a]); }
   }
   if (my_flag) atomicMax(&s_flag, my_flag);
   __syncthreads();
   // ---- phase 2 ----
   int flag = s_flag;
+  if (s_alloc > kVoxMaxRuns) flag = max(flag, kSmall ? 5 : 4);            // more runs than the pool holds
   const int mb0 = s_bb[0], mb1 = s_bb[1], mb2 = s_bb[2];
   const long long d0 = (long long)s_bb[3] - mb0 + 1, d1 = (long long)s_bb[4] - mb1 + 1, d2 = (long long)s_bb[5] - mb2 + 1;
   long long cells = 1;
@@ -1045,16 +1059,38 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
     if (!flag) { cells *= d2; if (cells > 0x7fffffffLL) flag = 1; }        // pcl: "leaf size too small", the cloud is not filtered
   }
   if (flag != 0 || n == 0) { if (tid == 0) { flags[b] = flag; m_out[b] = 0; } return; }
-  int wbase = 0, E = 0;                                    // runs before this wavefront's, all runs
-  for (int w = 0; w < kVoxWaves; w++) { const int c = s_wcount[w]; if (w < wave) wbase += c; E += c; }
-  for (int e = lane; e < s_wcount[wave]; e += 64) {
-    const int id = wave * kVoxRunsPerWave + e;
+  const int E = s_alloc;                                   // all runs
+  for (int id = tid; id < E; id += kThreads) {
     const unsigned long long r = s_run[id];
     const long long i0 = (long long)((int)(r >> 50) & 0x3fff) - 8192 - mb0, i1 = (long long)((int)(r >> 36) & 0x3fff) - 8192 - mb1,
                     i2 = (long long)((int)(r >> 22) & 0x3fff) - 8192 - mb2;
     const unsigned long long cell = (unsigned long long)(i0 + i1 * d0 + i2 * d0 * d1);
     s_run[id] = (cell << 22) | (r & 0x3fffffull);
-    s_ord(0)[wbase + e] = (unsigned short)id;              // run ids in arrival order
+  }
+  {
+    // run ids in ARRIVAL order: exclusive prefix of the chunk table's counts (entry c owned by thread c; unused entries are 0), then every
+    // wavefront lists the runs of its own chunks
+    static_assert(kMaxChunks <= kThreads, "one chunk-table entry per thread");
+    const int cnt = tid < kMaxChunks ? (int)s_ccnt[tid] : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int excl = incl - cnt;
+    for (int w = 0; w < wave; w++) excl += s_wsum[w];
+    // thread c now knows where chunk c's runs start in the arrival order; hand that to the wavefront that owns the chunk through
+    // the (now dead) count entry's neighbour array: s_hist is free until the sort
+    int* const c_at = reinterpret_cast<int*>(&s_hist[0][0]);             // kMaxChunks ints <= kVoxWaves * 256 * 2 bytes
+    static_assert(kMaxChunks * 4 <= kVoxWaves * 256 * 2, "chunk prefix fits the histogram area");
+    if (tid < kMaxChunks) c_at[tid] = excl;
+    __syncthreads();
+    const int n_chunks = (k1 > k0) ? ((k1 - k0 + 63) >> 6) : 0;
+    for (int c = 0; c < n_chunks; c++) {
+      const int ci = chunk0 + c;
+      const int cnt_c = s_ccnt[ci], base_c = s_cbase[ci], at_c = c_at[ci];
+      if (lane < cnt_c) s_ord(0)[at_c + lane] = (unsigned short)(base_c + lane);
+    }
   }
   int nbits = 1;
   while ((1ll << nbits) < cells) nbits++;
@@ -1147,7 +1183,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   if (tid == 0) { s_total = 0; s_nbig = 0; }
   __syncthreads();
   const float4* sums = run_sums + v.off[b];
-  auto sum_of = [&](int id) { return sums[(id / kVoxRunsPerWave) * seg + (id % kVoxRunsPerWave)]; };    // run id -> slice start + slot
+  auto sum_of = [&](int id) { return sums[id]; };            // run id = its slot in the cloud's pool
   // the later runs of voxel r added point by point to (sx, sy, sz, st); returns the voxel's point count
   auto later_runs = [&](int j0, int j1, float& sx, float& sy, float& sz, float& st) {
     int total = 0;

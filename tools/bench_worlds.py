@@ -53,7 +53,9 @@ def _register_stats(h, pipe, d_guess, sync, reps):
     return t_reg, k_ms, cand, n_feat
 
 
-def measure_worlds(device=0, checker=None, scans=256, reps=5, spot=3, kinds=("outdoor", "corridor")):
+def measure_worlds(device=0, checker=None, scans=256, reps=5, spot=3, kinds=("outdoor", "corridor"), copies=4):
+    """`scans` distinct sweeps per world, each registered from `copies` different guesses: scans x copies registrations per step (1 024
+    by default, the batch of bench.py's headline, so that registrations/s compare like for like; registrations are independent units)."""
     import torch
     from msf_loam_amd import capi, synth
     from msf_loam_amd.pipeline import BatchPipeline
@@ -65,10 +67,14 @@ def measure_worlds(device=0, checker=None, scans=256, reps=5, spot=3, kinds=("ou
         t0 = time.perf_counter()
         w = synth.World(kind=kind)
         mc, ms = synth.make_map(w)
-        truth = synth.world_poses(w, scans, synth.SEED + 2)
+        truth1 = synth.world_poses(w, scans, synth.SEED + 2)
+        raw1 = [synth.make_scan(w, truth1[i], synth.SEED + 100 + i) for i in range(scans)]
+        order = np.tile(np.arange(scans), copies)
+        n_sweeps, scans = scans, scans * copies
+        truth = truth1[order]
         rng = np.random.default_rng(synth.SEED + 3)
         guess = np.stack([synth.perturb_pose(p, rng) for p in truth])
-        raw = [synth.make_scan(w, truth[i], synth.SEED + 100 + i) for i in range(scans)]
+        raw = [raw1[i] for i in order]
         t_prep = time.perf_counter() - t0
         pts = np.concatenate([p for p, _ in raw]); ring = np.concatenate([r for _, r in raw])
         off = np.cumsum([0] + [len(p) for p, _ in raw]).astype(np.int32)
@@ -94,7 +100,7 @@ def measure_worlds(device=0, checker=None, scans=256, reps=5, spot=3, kinds=("ou
                 dmax = max(dmax, *synth.pose_error(poses[b], po))
                 same_counts = same_counts and rc == int(status[b])
             chk = {"scans": spot, "max_pose_delta": dmax, "tolerance": 1e-4, "ok": bool(dmax < 1e-4 and same_counts)}
-        out[kind] = {"scans": scans, "map_points": int(len(mc) + len(ms)), "map_corner": int(len(mc)), "map_surf": int(len(ms)),
+        out[kind] = {"scans": scans, "distinct_sweeps": n_sweeps, "map_points": int(len(mc) + len(ms)), "map_corner": int(len(mc)), "map_surf": int(len(ms)),
                      "points_per_scan": float(off[-1]) / scans, "features_per_scan": n_feat / scans,
                      "ms_per_step": 1e3 * t_reg, "registrations_per_s": scans / t_reg,
                      "kernels_ms": k_ms, "knn": {"candidates_per_query": cand},
@@ -106,6 +112,7 @@ def measure_worlds(device=0, checker=None, scans=256, reps=5, spot=3, kinds=("ou
                      "reference": "mapping_scan_matcher.cc:19-278 on worlds.py:" + kind}
         del pipe
         h.close()
+        scans = n_sweeps
     return out
 
 
