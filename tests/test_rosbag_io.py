@@ -68,7 +68,7 @@ def test_pointcloud2_layouts_and_refusals(tmp_path):
     no_ring = dict(pc, fields={k: v for k, v in pc["fields"].items() if k != "ring"})
     with pytest.raises(ValueError, match="ring"):
         rb.cloud_to_msfl(no_ring)
-    # not a bag / unsupported chunk compression
+    # not a bag / a chunk labelled lz4 whose payload is no LZ4 frame
     bad = tmp_path / "x.bag"
     bad.write_bytes(b"not a bag")
     with pytest.raises(ValueError):
@@ -86,6 +86,125 @@ def test_pointcloud2_layouts_and_refusals(tmp_path):
     open(p, "wb").write(patched)
     with pytest.raises(ValueError, match="lz4"):
         list(rb.BagReader(p).messages())
+
+
+def test_lz4_block_and_frame_known_answers():
+    """Hand-assembled bytes from the published LZ4 block / frame formats: literals + an overlapping match, 255-extended
+    literal and match lengths, a run (offset 1), a stored block, the end mark; and the refusals."""
+    # "abc" + match(offset 3, length 9: overlaps its own output) + last literals
+    assert rb.lz4_block_decompress(bytes([0x35]) + b"abc" + bytes([3, 0]) + bytes([0x50]) + b"xyz12") == b"abc" + b"abc" * 3 + b"xyz12"
+    # 273 literals: 15 in the token, then 255 + 3
+    lit = bytes(range(256)) + bytes(range(17))
+    assert rb.lz4_block_decompress(bytes([0xF0, 255, 3]) + lit) == lit
+    # a run: one literal, match offset 1 of length 300 (15 in the token + 255 + 26, + 4), then five literals
+    assert rb.lz4_block_decompress(bytes([0x1F]) + b"a" + bytes([1, 0, 255, 26]) + bytes([0x50]) + b"bbbbb") == b"a" * 301 + b"bbbbb"
+    # match reaching back across an earlier match
+    assert rb.lz4_block_decompress(bytes([0x40]) + b"0123" + bytes([4, 0]) + bytes([0x00, 8, 0]) + bytes([0x50]) + b"ABCDE") == b"0123" * 2 + b"0123" + b"ABCDE"
+    for bad in (bytes([0x10]) + b"a" + bytes([2, 0]) + bytes([0x50]) + b"bbbbb",       # offset beyond the output
+                bytes([0x10]) + b"a" + bytes([0, 0]) + bytes([0x50]) + b"bbbbb",       # offset 0
+                bytes([0xF0, 255]),                                                    # truncated length
+                bytes([0x30]) + b"ab"):                                                # literals past the end
+        with pytest.raises(ValueError, match="lz4 block"):
+            rb.lz4_block_decompress(bad)
+    # a frame by hand: magic, FLG = version 1 | independent blocks, BD = 64 KB, header checksum, one compressed and one stored block, end mark
+    try:
+        import xxhash
+        hc = (xxhash.xxh32(bytes([0x60, 0x40]), seed=0).intdigest() >> 8) & 0xff
+    except ImportError:
+        hc = 0
+    blk = bytes([0x35]) + b"abc" + bytes([3, 0]) + bytes([0x50]) + b"xyz12"
+    frame = struct.pack("<I", 0x184D2204) + bytes([0x60, 0x40, hc]) + struct.pack("<I", len(blk)) + blk + struct.pack("<I", 5 | 0x80000000) + b"STORE" + struct.pack("<I", 0)
+    assert rb.lz4_frame_decompress(frame) == b"abc" * 4 + b"xyz12" + b"STORE"
+    with pytest.raises(ValueError, match="record says"):
+        rb.lz4_frame_decompress(frame, expect_size=3)
+    with pytest.raises(ValueError, match="magic"):
+        rb.lz4_frame_decompress(b"\x00" * 16)
+    with pytest.raises(ValueError, match="truncated"):
+        rb.lz4_frame_decompress(frame[:-4])
+    # the module's own encoder (used by the writer for fixtures) against the decoder on awkward inputs
+    rng = np.random.default_rng(1)
+    for data in (b"", b"x", b"hello hello hello hello", bytes(rng.integers(0, 3, 20000, dtype=np.uint8)), bytes(rng.integers(0, 256, 70000, dtype=np.uint8)), b"abcdefgh" * 20000):
+        assert rb.lz4_frame_decompress(rb.lz4_frame_compress(data), len(data)) == data
+
+
+def test_lz4_bag_round_trip_and_time_merge(tmp_path):
+    rng = np.random.default_rng(3)
+    clouds = [(rng.normal(size=(300 + 11 * k, 4)).astype(np.float32), rng.integers(0, 16, 300 + 11 * k).astype(np.uint16)) for k in range(7)]
+    p = str(tmp_path / "l.bag")
+    _write(p, clouds, "lz4", per=3)
+    assert b"compression=lz4" in open(p, "rb").read()
+    got = list(rb.BagReader(p).messages())
+    assert len(got) == 14
+    for k, (pts, ring) in enumerate(clouds):
+        a, b = rb.cloud_to_msfl(rb.parse_pointcloud2(got[2 * k][3]))
+        assert np.array_equal(a, pts) and np.array_equal(b, ring)
+    # a bag whose chunks are NOT in time order (re-indexed / merged bags): IMU written first, then the clouds
+    q = str(tmp_path / "m.bag")
+    w = rb.BagWriter(q, compression="lz4", chunk_messages=4)
+    for k in range(6):
+        w.write("/imu/data", "sensor_msgs/Imu", 1000.05 + 0.1 * k, rb.serialize_imu(1000.05 + 0.1 * k, "imu", [0, 0, 0, 1], [k, 0, 0], [0, 0, 9.8]))
+    for k, (pts, ring) in enumerate(clouds[:6]):
+        w.write("/velodyne_points", "sensor_msgs/PointCloud2", 1000.0 + 0.1 * k, rb.serialize_pointcloud2(1000.0 + 0.1 * k, "velodyne", pts, ring, k))
+    w.close()
+    in_file = [g[0] for g in rb.BagReader(q).messages(by_time=False)]
+    assert in_file == ["/imu/data"] * 6 + ["/velodyne_points"] * 6
+    merged = list(rb.BagReader(q).messages())                         # like rosbag::View: by record time
+    assert [g[0] for g in merged] == ["/velodyne_points", "/imu/data"] * 6
+    assert all(merged[i][2] <= merged[i + 1][2] for i in range(11))
+    assert rb.parse_imu(merged[3][3])["angular_velocity"][0] == 1.0
+    only = list(rb.BagReader(q).messages(topics=["/velodyne_points"]))
+    assert len(only) == 6 and np.array_equal(rb.cloud_to_msfl(rb.parse_pointcloud2(only[5][3]))[0], clouds[5][0])
+
+
+def test_truncated_files_and_messages_raise_value_errors(tmp_path):
+    rng = np.random.default_rng(4)
+    clouds = [(rng.normal(size=(100, 4)).astype(np.float32), rng.integers(0, 16, 100).astype(np.uint16)) for _ in range(4)]
+    p = str(tmp_path / "t.bag")
+    _write(p, clouds, "none", per=2)
+    raw = open(p, "rb").read()
+    for cut in (len(raw) - 7, len(raw) - 3000, 4096 + 9):
+        q = tmp_path / ("cut%d.bag" % cut)
+        q.write_bytes(raw[:cut])
+        with pytest.raises(ValueError):
+            list(rb.BagReader(str(q)).messages())
+    msg = rb.serialize_pointcloud2(1.0, "v", *clouds[0])
+    with pytest.raises(ValueError, match="truncated"):
+        rb.parse_pointcloud2(msg[:-900])                              # the data blob is shorter than width x point_step
+
+
+def test_velodyne_driver_point_layouts():
+    """The two layouts Velodyne's ROS driver has published, assembled by hand:
+    packed PointXYZIRT  x y z intensity @0/4/8/12, ring u16 @16, time f32 @18 (UNALIGNED), point_step 22;
+    PCL-aligned         x y z @0/4/8, intensity @16, ring u16 @20, time f32 @24, point_step 32 (the reference's struct, common.h:44-62).
+    Both must give the same (x y z intensity, ring) arrays; the reference reads by field NAME through pcl::fromROSMsg."""
+    rng = np.random.default_rng(5)
+    n = 37
+    xyz_i = rng.normal(size=(n, 4)).astype(np.float32)
+    ring = rng.integers(0, 16, n).astype(np.uint16)
+    tm = rng.uniform(0, 0.1, n).astype(np.float32)
+
+    def msg(fields, step, fill):
+        hdr = struct.pack("<III", 1, 100, 0) + struct.pack("<I", 8) + b"velodyne"
+        body = hdr + struct.pack("<II", 1, n) + struct.pack("<I", len(fields))
+        for name, off, dt in fields:
+            body += struct.pack("<I", len(name)) + name.encode() + struct.pack("<IBI", off, dt, 1)
+        blob = bytearray(n * step)
+        for k in range(n):
+            fill(blob, k * step, k)
+        return body + struct.pack("<BII", 0, step, step * n) + struct.pack("<I", len(blob)) + bytes(blob) + b"\x01"
+
+    def fill22(b, o, k):
+        b[o:o + 16] = xyz_i[k].tobytes(); b[o + 16:o + 18] = struct.pack("<H", ring[k]); b[o + 18:o + 22] = struct.pack("<f", tm[k])
+
+    def fill32(b, o, k):
+        b[o:o + 12] = xyz_i[k, :3].tobytes(); b[o + 16:o + 20] = xyz_i[k, 3:].tobytes(); b[o + 20:o + 22] = struct.pack("<H", ring[k]); b[o + 24:o + 28] = struct.pack("<f", tm[k])
+    packed = rb.parse_pointcloud2(msg([("x", 0, 7), ("y", 4, 7), ("z", 8, 7), ("intensity", 12, 7), ("ring", 16, 4), ("time", 18, 7)], 22, fill22))
+    aligned = rb.parse_pointcloud2(msg([("x", 0, 7), ("y", 4, 7), ("z", 8, 7), ("intensity", 16, 7), ("ring", 20, 4), ("time", 24, 7)], 32, fill32))
+    for pc in (packed, aligned):
+        pts, r = rb.cloud_to_msfl(pc)
+        assert np.array_equal(pts, xyz_i) and np.array_equal(r, ring) and np.array_equal(pc["fields"]["time"], tm)
+    with pytest.raises(ValueError, match="does not fit"):
+        rb.parse_pointcloud2(msg([("x", 0, 7), ("y", 4, 7), ("z", 8, 7), ("ring", 21, 4)], 22, fill22))
 
 
 @pytest.mark.gpu
