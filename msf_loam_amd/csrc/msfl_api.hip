@@ -134,6 +134,11 @@ struct msfl_handle_s {
   int grid_cap_cells = 64 * 1024 * 1024;  // hard limit of the dense cell table (MSFL_GRID_CAP_CELLS)
   int h2d_chunk_scans = 512;              // MSFL_H2D_CHUNK_SCANS: scans per PCIe chunk of a host-buffer batch (>= 2 chunks to pipeline)
   int h2d_sub_chunks = 2;                 // MSFL_H2D_SUB_CHUNKS: pieces a chunk arrives in (its first association pass follows them)
+  // set by msfl_voxel_downsample_batch when it refuses a cloud for a non-finite point: the cloud's number (-1: none) and where its
+  // points are on the device (the staged copy of a host batch, or the caller's device array).  msfl_voxel_downsample reads these,
+  // not the error text, to run PCL's drop-the-non-finite-points path.
+  int vox_nonfinite_cloud = -1;
+  const float4* vox_staged_pts = nullptr;
   bool voxel_force_global = false;        // MSFL_VOXEL_GLOBAL=1: the batched voxel filter keeps the device-wide radix-sort form (A/B testing)
   long long odom_wave_max_targets = -1;   // MSFL_ODOM_WAVE_MAX_TARGETS: previous-scan points up to which a small batch takes the one-wavefront-per-query kernel (default 4096 per pair)
   bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)

@@ -236,6 +236,11 @@ __device__ __forceinline__ float top_d4(const Top5& t) { return top5_d4(t); }
 #ifndef MSFL_TOP5_SELECT
 #define MSFL_TOP5_SELECT 0          /* 1: the compare / select insertion network of rounds 1-3 (A/B) */
 #endif
+// The inline assembly below (v_min_f64 / v_max_f64 / v_med3_u32 by their gfx950 mnemonics) is written for the one target this library
+// has: a device pass for anything else stops here with a message instead of an assembler error deep in a template.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libmsfl_hip is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
 // unsigned 64-bit min / max of two keys whose high words are < 2^31, on the f64 min / max unit (see top5_insert)
 __device__ __forceinline__ unsigned long long u64_min_f(unsigned long long a, unsigned long long b) {
   double r;

@@ -164,3 +164,56 @@ def test_mapping_thread_gives_the_same_poses(monkeypatch):
         est, recs, _ = rp.run_slam(world, truth, pipelined=pipelined, scans=scans, maps_out=maps)
         assert np.array_equal(est, ref)
         assert [list(r.grid_surf)[:2] for r in recs] == [list(r.grid_surf)[:2] for r in recs0]
+
+
+@pytest.mark.parametrize("threads", ["0", "1"])
+def test_a_poisoned_pipeline_still_hands_out_the_earlier_results(monkeypatch, threads):
+    """a failure in the middle of scan k's chain poisons the pipeline (every later msfl_slam_add_scan returns the stored
+    error) but the records of the scans whose chains were completely enqueued BEFORE it stay fetchable, as msfl_slam_add_scan_imu's
+    contract says; msfl_slam_grids still works.  The failure is injected (MSFL_SLAM_FAIL_AT): nothing in a healthy run produces one."""
+    from msf_loam_amd import capi
+    truth, scans = _scans(6)
+    ref = capi.Slam(0, max_scan_points=max(len(p) for p, _ in scans), max_rings=16, pose_odom2map=truth[0])
+    want = [np.array(ref.add_scan(*scans[k]).pose_map[:]) for k in range(3)]
+    ref.close()
+    monkeypatch.setenv("MSFL_SLAM_THREADS", threads)
+    monkeypatch.setenv("MSFL_SLAM_FAIL_AT", "3")
+    slam = capi.Slam(0, max_scan_points=max(len(p) for p, _ in scans), max_rings=16, pose_odom2map=truth[0])
+    try:
+        for k in range(3):
+            slam.add_scan(*scans[k], wait=False)
+        failed = False
+        try:
+            slam.add_scan(*scans[3], wait=False)        # single-thread form: fails here; mapping thread: the failure surfaces at the next wait
+        except capi.MsflError as e:
+            failed = True
+            assert e.status == capi.HIP_ERROR and "injected" in str(e)
+        for k in (1, 2):                                # fetched AFTER the failure
+            assert np.array_equal(np.array(slam.result(k).pose_map[:]), want[k]), k
+        with pytest.raises(capi.MsflError) as e3:       # the failed scan itself has no result
+            slam.result(3)
+        assert e3.value.status == capi.HIP_ERROR
+        with pytest.raises(capi.MsflError) as e4:       # and nothing follows it
+            slam.add_scan(*scans[4], wait=False)
+        assert e4.value.status == capi.HIP_ERROR
+        assert failed or threads == "1"
+        gc_, gs_ = slam.grids()                         # the stores are still readable (what scans 0-2 inserted)
+        assert gs_.size()[0] > 1000
+    finally:
+        slam.close()
+
+
+def test_batches_beyond_the_2d_launch_limit_are_refused_up_front(gpu):
+    """kernels launched 2-D over (tile, scan / pair) cannot take more than 65 535 rows: MSFL_CAPACITY with a message, before
+    any staging, instead of an opaque HIP launch error."""
+    import ctypes as C
+    from msf_loam_amd import capi
+    P = 65536
+    z = np.zeros(P + 1, np.int32)
+    poses = np.zeros((P, 7)); status = np.zeros(P, np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    s = gpu.lib.msfl_match_pairs_batch(gpu.h, C.c_int(P), None, vp(z), None, vp(z), None, vp(z), None, vp(z), vp(poses), vp(status), None, C.c_int(capi.MEM_HOST))
+    assert s == capi.CAPACITY and b"65535" in gpu.lib.msfl_last_error(gpu.h)
+    fb = capi.FeaturesBatch()
+    s = gpu.lib.msfl_extract_features_batch(gpu.h, C.c_int(P), None, None, vp(z), C.byref(fb), vp(status), C.c_int(capi.MEM_HOST))
+    assert s == capi.CAPACITY and b"65535" in gpu.lib.msfl_last_error(gpu.h)
