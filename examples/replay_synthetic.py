@@ -110,7 +110,7 @@ def synthetic_imu(poses_true, switch_at=50, seed=synth.SEED + 900, samples=45):
     return out
 
 
-def run(backend, world, poses_true, verbose=False, maps_out=None, scans=None, quirks=False, imu=None):
+def run(backend, world, poses_true, verbose=False, maps_out=None, scans=None, quirks=False, imu=None, clouds_out=None):
     """quirks: FilterLessFlatLessCornerFeature as the reference executes it (laser_mapping.cc:340-364: the surf cloud cut to its first
     n_less_sharp points).  imu: per-scan dicts (synthetic_imu) -> UndistortScan before the match while not initialised
     (:170-176), the is_initialized matcher branch + DoUndistort before the insert afterwards (:197-211); needs a backend with
@@ -162,6 +162,16 @@ def run(backend, world, poses_true, verbose=False, maps_out=None, scans=None, qu
         if im is not None and im["is_initialized"]:                           # DoUndistort, laser_mapping.cc:197-211 (pose_odom_scan2world_!)
             ls = backend.deskew(pre, ls, odo2first[3:], im["velocity"], im["gravity"])
             lf = backend.deskew(pre, lf, odo2first[3:], im["velocity"], im["gravity"])
+        if clouds_out is not None:
+            # the data products that reach neither the pose nor the map: cloud_full_res after the scan's IMU passes (UndistortScan
+            # :170-176 / DoUndistort :206) and TransformPointCloud(cloud_full_res, pose_map_scan2world_) (:214-217)
+            full = f["full"]
+            if im is not None and not im["is_initialized"]:
+                full = backend.undistort(pre, full)
+            elif im is not None:
+                full = backend.deskew(pre, full, odo2first[3:], im["velocity"], im["gravity"])
+            clouds_out.append(dict(full_scan=full, full_map=transform_(pose_map, full), ring=f["ring"], sharp=f["sharp"], less_sharp=f["less_sharp"],
+                                   flat=f["flat"], less_flat=f["less_flat"]))
         grid_c.insert_scan(transform_(pose_map, ls))                          # InsertScan2Map, laser_mapping.cc:330-338
         grid_s.insert_scan(transform_(pose_map, lf))
         t5 = time.perf_counter()
@@ -179,7 +189,7 @@ def run(backend, world, poses_true, verbose=False, maps_out=None, scans=None, qu
     return np.array(est), {k: 1e3 * v / m for k, v in t_stage.items()}
 
 
-def run_slam(world, poses_true, pipelined=False, device=0, scans=None, verbose=False, maps_out=None, quirks=False, imu=None):
+def run_slam(world, poses_true, pipelined=False, device=0, scans=None, verbose=False, maps_out=None, quirks=False, imu=None, clouds_out=None):
     """The same loop through the device-resident SLAM step (msfl_slam_add_scan): raw scan in, pose out, one
     synchronisation per scan (pipelined=False) or none until the record is fetched one scan later (pipelined=True: the
     odometry chain of scan k + 1 runs under the mapping chain of scan k, like the reference's two threads).
@@ -190,7 +200,7 @@ def run_slam(world, poses_true, pipelined=False, device=0, scans=None, verbose=F
         scans = [synth.make_scan(world, poses_true[k], synth.SEED + 5000 + k) for k in range(n)]
     cap = max(len(p) for p, _ in scans)
     slam = capi.Slam(device, max_scan_points=cap, max_rings=int(max(r.max() for _, r in scans)) + 1, pose_odom2map=poses_true[0],
-                     reference_quirks=1 if quirks else 0)
+                     reference_quirks=1 if quirks else 0, keep_clouds=1 if clouds_out is not None else 0)
     recs = [None] * n
     t_start = None
     for k in range(n):
@@ -201,13 +211,19 @@ def run_slam(world, poses_true, pipelined=False, device=0, scans=None, verbose=F
             slam.add_scan(*scans[k], wait=False, imu=im)
             if k >= 1:
                 recs[k - 1] = slam.result(k - 1)
+                if clouds_out is not None:
+                    clouds_out.append(slam.clouds(k - 1))
         else:
             recs[k] = slam.add_scan(*scans[k], imu=im)
+            if clouds_out is not None:
+                clouds_out.append(slam.clouds(k))
         if verbose and k % 50 == 0 and recs[max(k - 1, 0)] is not None:
             r = recs[max(k - 1, 0)]
             print(k, list(r.grid_corner)[:3], list(r.grid_surf)[:3], r.status_mapping, file=sys.stderr)
     if pipelined:
         recs[n - 1] = slam.result(n - 1)
+        if clouds_out is not None:
+            clouds_out.append(slam.clouds(n - 1))
     wall = time.perf_counter() - t_start if t_start is not None else 0.0
     est = np.array([np.array(r.pose_map[:]) for r in recs])
     if maps_out is not None:

@@ -536,6 +536,12 @@ typedef struct msfl_slam_config {
         less-flat points makes the reference read out of bounds (pcl::copyPointCloud); here: status_mapping = MSFL_BAD_ARG,
         status_imu untouched, the scan is neither matched nor inserted. */
   int    reference_quirks;
+  /* 1: also produce the data products of LaserMapping::Run that reach neither the pose nor the map (round 5): cloud_full_res after
+        the scan's IMU passes (UndistortScan :170-176 while not initialised, DoUndistort :206 once it is; untouched without IMU data)
+        and its copy in the map frame, TransformPointCloud(cloud_full_res, pose_map_scan2world_) (:214-217: what the reference
+        accumulates for its PLY dump and publishes), fetched with msfl_slam_get_clouds; the sharp / flat / less-sharp / less-flat
+        clouds of PublishScan (:418-440) are index lists into that cloud.  One more launch per scan.  0 (default): not computed. */
+  int    keep_clouds;
 } msfl_slam_config;
 
 typedef struct msfl_slam_result {
@@ -558,6 +564,10 @@ typedef struct msfl_slam_result {
                                  the scan is then neither matched nor inserted (status_mapping = MSFL_BAD_ARG as well) */
   int status_insert;          /* 0, or MSFL_CAPACITY: one of the two InsertScan calls was dropped (grid_*[3] / [4] != 0: a point outside
                                  the +-8192-cell range / not finite, or an internal capacity); the map store is then unchanged */
+  int status_clouds;          /* keep_clouds: 0, or MSFL_BAD_ARG: a point of cloud_full_res OUTSIDE the less-sharp / less-flat lists (ring
+                                 margins, corner neighbourhoods) has a relative time outside the pre-integration span; the reference
+                                 CHECK-aborts on it inside UndistortScan / DoUndistort, here that point is left as it was */
+  int reserved_;
 } msfl_slam_result;
 
 void msfl_slam_default_config(msfl_slam_config* c);
@@ -593,8 +603,8 @@ msfl_status msfl_slam_add_scan(msfl_slam* s, const msfl_point* pts, const uint16
    The odometry thread (MatchScan2Scan) never sees any of this: it works on the raw feature clouds (laser_odometry.cc:69-95).
    Which clouds: cloud_corner_less_sharp and cloud_surf_less_flat, the two that reach the pose and the map.  The reference also
    rewrites cloud_full_res (published / accumulated for the PLY dump only) and, in the not-initialised branch, the sharp / flat clouds,
-   which nothing reads afterwards (FilterLessFlatLessCornerFeature hands on EMPTY sharp / flat clouds, :344-345); for those use
-   msfl_undistort_cloud / msfl_deskew_cloud on the extraction output.
+   which nothing reads afterwards (FilterLessFlatLessCornerFeature hands on EMPTY sharp / flat clouds, :344-345): with
+   msfl_slam_config.keep_clouds = 1 the step produces those too (msfl_slam_get_clouds).
    `pre` holds at most 2 048 samples (MSFL_CAPACITY beyond); the arrays are copied before the call returns. */
 typedef struct msfl_slam_imu {
   const msfl_preintegration* pre;
@@ -611,6 +621,21 @@ msfl_status msfl_slam_add_scan_imu(msfl_slam* s, const msfl_point* pts, const ui
 
 /* Wait for the scan with the given index (one of the last four fed) and deliver its record. */
 msfl_status msfl_slam_get_result(msfl_slam* s, int scan_index, msfl_slam_result* result);
+
+/* msfl_slam_config.keep_clouds: the clouds of scan `scan_index` (it must be one of the last TWO fed: the buffers belong to a set that
+   the scan after next reuses).  Waits for that scan's chain.
+     mem == MSFL_MEM_DEVICE: the function FILLS the pointers with device addresses (valid until msfl_slam_add_scan of scan_index + 2);
+     mem == MSFL_MEM_HOST  : the CALLER fills the pointers it wants (NULL = not wanted) with host arrays of max_scan_points elements
+                             each and the function copies.
+   Counts are always delivered.  index lists address points of `full_scan` / `full_map` / `ring`. */
+typedef struct msfl_slam_clouds {
+  msfl_point* full_scan;      /* cloud_full_res in the scan frame after the IMU passes of LaserMapping::Run (:170-176,:206) */
+  msfl_point* full_map;       /* TransformPointCloud(cloud_full_res, pose_map_scan2world_) (:214-217), f32 */
+  uint16_t*   ring;           /* ring id of every point of the full cloud */
+  int *sharp_idx, *less_sharp_idx, *flat_idx, *less_flat_idx;   /* msf_loam_node.cc:279-344 as positions in the full cloud */
+  int n_full, n_sharp, n_less_sharp, n_flat, n_less_flat;
+} msfl_slam_clouds;
+msfl_status msfl_slam_get_clouds(msfl_slam* s, int scan_index, msfl_slam_clouds* clouds, msfl_mem mem);
 
 /* The two map stores (hybrid_grid_map_corner_ / hybrid_grid_map_surf_), e.g. for msfl_grid_dump at shutdown
    (laser_mapping.cc:95-113).  Owned by the pipeline; do not destroy.  Waits for everything in flight. */

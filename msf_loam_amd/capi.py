@@ -27,7 +27,7 @@ EXPORTED = [
     "msfl_delta_qp", "msfl_deskew_cloud", "msfl_undistort_cloud",
     "msfl_grid_create", "msfl_grid_destroy", "msfl_grid_insert_scan", "msfl_grid_get_surrounded", "msfl_grid_size", "msfl_grid_dump",
     "msfl_slam_default_config", "msfl_slam_create", "msfl_slam_destroy", "msfl_slam_add_scan", "msfl_slam_add_scan_imu", "msfl_slam_get_result", "msfl_slam_grids",
-    "msfl_slam_last_error",
+    "msfl_slam_last_error", "msfl_slam_get_clouds",
 ]
 
 
@@ -108,7 +108,14 @@ class FeaturesBatch(C.Structure):
 class SlamConfig(C.Structure):
     _fields_ = [("map_resolution", C.c_float), ("leaf_corner", C.c_float), ("leaf_surf", C.c_float),
                 ("min_map_corner", C.c_int), ("min_map_surf", C.c_int), ("max_scan_points", C.c_int), ("max_rings", C.c_int),
-                ("pose_odom2map", C.c_double * 7), ("reference_quirks", C.c_int)]
+                ("pose_odom2map", C.c_double * 7), ("reference_quirks", C.c_int), ("keep_clouds", C.c_int)]
+
+
+class SlamClouds(C.Structure):
+    """msfl_slam_clouds: cloud_full_res after the IMU passes, its map-frame copy, ring ids and the four index lists (keep_clouds)."""
+    _fields_ = [("full_scan", C.c_void_p), ("full_map", C.c_void_p), ("ring", C.c_void_p),
+                ("sharp_idx", C.c_void_p), ("less_sharp_idx", C.c_void_p), ("flat_idx", C.c_void_p), ("less_flat_idx", C.c_void_p),
+                ("n_full", C.c_int), ("n_sharp", C.c_int), ("n_less_sharp", C.c_int), ("n_flat", C.c_int), ("n_less_flat", C.c_int)]
 
 
 class SlamImu(C.Structure):
@@ -123,7 +130,8 @@ class SlamResult(C.Structure):
                 ("scan_index", C.c_int), ("status_extract", C.c_int), ("status_mapping", C.c_int),
                 ("n_full", C.c_int), ("n_sharp", C.c_int), ("n_less_sharp", C.c_int), ("n_flat", C.c_int), ("n_less_flat", C.c_int),
                 ("n_corner_ds", C.c_int), ("n_surf_ds", C.c_int), ("n_map_corner", C.c_int), ("n_map_surf", C.c_int),
-                ("grid_corner", C.c_int * 8), ("grid_surf", C.c_int * 8), ("status_imu", C.c_int), ("status_insert", C.c_int)]
+                ("grid_corner", C.c_int * 8), ("grid_surf", C.c_int * 8), ("status_imu", C.c_int), ("status_insert", C.c_int),
+                ("status_clouds", C.c_int), ("reserved_", C.c_int)]
 
 
 class MsflError(RuntimeError):
@@ -572,6 +580,7 @@ class Slam:
         c = SlamConfig()
         self.lib.msfl_slam_default_config(C.byref(c))
         c.max_scan_points, c.max_rings = int(max_scan_points), int(max_rings)
+        self.max_scan_points = int(max_scan_points)
         if pose_odom2map is not None:
             for k in range(7):
                 c.pose_odom2map[k] = float(pose_odom2map[k])
@@ -646,6 +655,22 @@ class Slam:
         if st != OK:
             raise MsflError(st, "msfl_slam_get_result", self._err())
         return r
+
+    def clouds(self, scan_index):
+        """keep_clouds=1: the scan's data products as host arrays (msfl_slam_get_clouds, MSFL_MEM_HOST): dict with full_scan (n,4),
+        full_map (n,4), ring (n,), sharp / less_sharp / flat / less_flat index arrays.  Only for one of the last two scans fed."""
+        n = self.max_scan_points
+        full_scan, full_map = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
+        ring = np.zeros(n, np.uint16)
+        idx = [np.zeros(n, np.int32) for _ in range(4)]
+        c = SlamClouds()
+        c.full_scan, c.full_map, c.ring = full_scan.ctypes.data, full_map.ctypes.data, ring.ctypes.data
+        c.sharp_idx, c.less_sharp_idx, c.flat_idx, c.less_flat_idx = (a.ctypes.data for a in idx)
+        st = self.lib.msfl_slam_get_clouds(self.s, C.c_int(int(scan_index)), C.byref(c), C.c_int(MEM_HOST))
+        if st != OK:
+            raise MsflError(st, "msfl_slam_get_clouds", self._err())
+        return dict(full_scan=full_scan[:c.n_full], full_map=full_map[:c.n_full], ring=ring[:c.n_full], sharp=idx[0][:c.n_sharp],
+                    less_sharp=idx[1][:c.n_less_sharp], flat=idx[2][:c.n_flat], less_flat=idx[3][:c.n_less_flat])
 
     def grids(self):
         a, b = C.c_void_p(), C.c_void_p()

@@ -17,7 +17,8 @@ namespace msfl {
 
 // counts block of one scan, written by the extraction kernels: [n_full, n_sharp, n_less_sharp, n_flat, n_less_flat, status, -, -]
 enum { SC_FULL = 0, SC_SHARP, SC_LESS_SHARP, SC_FLAT, SC_LESS_FLAT, SC_STATUS, SC_OVERFLOW, SC_USE_LS, SC_USE_LF, SC_IMU_BAD, SC_QUIRK_OOB,
-       SC_WORDS = 12 };
+       SC_CLOUD_BAD, SC_WORDS = 12 };
+// SC_CLOUD_BAD (keep_clouds): a point of the full cloud outside the two validated lists has a time stamp outside the pre-integration span
 // SC_IMU_BAD: a less-sharp / less-flat point's time lies outside the scan's pre-integration span (raised by the gather kernel's lanes,
 // cleared by slam_result_kernel once the record is assembled); SC_QUIRK_OOB: reference_quirks and more less-sharp than less-flat points
 // SC_USE_LS / SC_USE_LF: the less-sharp / less-flat counts the mapping thread works with: the extraction's, or 0 for a scan that is
@@ -210,6 +211,47 @@ slam_deskew_kernel(const SlamImuDev* __restrict__ imu, const double* __restrict_
   const d3 b = quat_rotate(rc, m);
   e.x = (float)(a.x + b.x + o.p.x); e.y = (float)(a.y + b.y + o.p.y); e.z = (float)(a.z + b.z + o.p.z);
   pts[i] = e;
+}
+
+// msfl_slam_config.keep_clouds: the data products of LaserMapping::Run that reach neither the pose nor the map.  One thread per point of
+// cloud_full_res, after TransformUpdate:
+//   full_scan[i]  mode 0: the point as extracted; mode 1: UndistortScanInternal (scan_undistortion.cc:5-19, run by UndistortScan before
+//                 the match, laser_mapping.cc:170-176); mode 2: DoUndistort (laser_mapping.cc:198-206) — the arithmetic of
+//                 slam_map_point / slam_deskew_kernel, so a listed point equals its copy in map_ls / map_lf bit for bit
+//   full_map[i]   TransformPointCloud(cloud_full_res, pose_map_scan2world_) (laser_mapping.cc:214-217, rigid_transform.h:131-137)
+// A time stamp outside the pre-integration span (the reference CHECK-aborts, scan_undistortion.cc:12,26-30) leaves the point as it
+// was and raises cnt[SC_CLOUD_BAD].
+__global__ void __launch_bounds__(256)
+slam_full_cloud_kernel(const SlamImuDev* __restrict__ imu, const double* __restrict__ pose_odom, const double* __restrict__ pose_map,
+                       int* __restrict__ cnt, const float4* __restrict__ full, int n_cap, float4* __restrict__ full_scan,
+                       float4* __restrict__ full_map) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = cnt[SC_STATUS] == 0 ? min(cnt[SC_FULL], n_cap) : 0;
+  if (i >= n) return;
+  float4 e = full[i];
+  const int mode = imu->mode;
+  if (mode != 0) {
+    const double dt = (double)e.w;
+    const DeltaQP o = delta_qp(slam_preint(imu), dt);
+    if (!o.ok || (mode == 1 && !(e.w >= 0.f))) cnt[SC_CLOUD_BAD] = 1;
+    else if (mode == 1) {
+      const float qx = (float)o.q.x, qy = (float)o.q.y, qz = (float)o.q.z, qw = (float)o.q.w;
+      float ux = qy * e.z - qz * e.y, uy = qz * e.x - qx * e.z, uz = qx * e.y - qy * e.x;
+      ux += ux; uy += uy; uz += uz;
+      const float cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
+      e.x = e.x + qw * ux + cx; e.y = e.y + qw * uy + cy; e.z = e.z + qw * uz + cz;
+    } else {
+      quat rc; rc.x = -pose_odom[3]; rc.y = -pose_odom[4]; rc.z = -pose_odom[5]; rc.w = pose_odom[6];
+      const d3 a = quat_rotate(o.q, mk3((double)e.x, (double)e.y, (double)e.z));
+      const d3 m = mk3(imu->velocity[0] * dt - 0.5 * imu->gravity[0] * dt * dt, imu->velocity[1] * dt - 0.5 * imu->gravity[1] * dt * dt,
+                       imu->velocity[2] * dt - 0.5 * imu->gravity[2] * dt * dt);
+      const d3 b = quat_rotate(rc, m);
+      e.x = (float)(a.x + b.x + o.p.x); e.y = (float)(a.y + b.y + o.p.y); e.z = (float)(a.z + b.z + o.p.z);
+    }
+  }
+  full_scan[i] = e;
+  const float3 q = transform_point_f32(load_pose(pose_map), e.x, e.y, e.z);
+  full_map[i] = make_float4(q.x, q.y, q.z, e.w);
 }
 
 // ---- voxel filter of ONE list of more than 65 535 points (a 64-beam less-flat list), device-sized --------------------

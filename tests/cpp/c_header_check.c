@@ -14,7 +14,8 @@ int main(void) {
                        (const void*)msfl_transform_cloud, (const void*)msfl_delta_qp, (const void*)msfl_deskew_cloud, (const void*)msfl_undistort_cloud,
                        (const void*)msfl_grid_create, (const void*)msfl_grid_insert_scan, (const void*)msfl_grid_get_surrounded,
                        (const void*)msfl_slam_create, (const void*)msfl_slam_add_scan, (const void*)msfl_slam_get_result, (const void*)msfl_slam_grids,
-                       (const void*)msfl_slam_destroy, (const void*)msfl_slam_add_scan_imu, (const void*)msfl_match_pairs_batch};
+                       (const void*)msfl_slam_destroy, (const void*)msfl_slam_add_scan_imu, (const void*)msfl_match_pairs_batch,
+                       (const void*)msfl_slam_get_clouds};
   size_t n = sizeof(fns) / sizeof(fns[0]), i, ok = 0;
   for (i = 0; i < n; i++) ok += fns[i] != NULL;
   printf("api %d, %zu entry points, sizeof(msfl_point)=%zu, sizeof(msfl_slam_result)=%zu, outer_iterations=%d\n", msfl_api_version(), ok, sizeof(msfl_point),

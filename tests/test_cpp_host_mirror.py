@@ -40,7 +40,7 @@ def test_header_is_plain_c_and_links():
     exe = os.path.join(ROOT, "tests", "cpp", "c_header_check")
     assert os.path.exists(exe)
     out = subprocess.check_output([exe]).decode()         # pure host calls: default params, API version, symbol addresses
-    assert "28 entry points" in out and "sizeof(msfl_point)=16" in out and "sizeof(msfl_slam_result)=488" in out
+    assert "29 entry points" in out and "sizeof(msfl_point)=16" in out and "sizeof(msfl_slam_result)=496" in out
 
 
 @pytest.mark.gpu

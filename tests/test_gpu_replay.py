@@ -332,3 +332,78 @@ def test_device_resident_slam_step_in_the_other_worlds(oracle, kind):
         assert rp.ate(est_g, truth) > 5.0                      # and loses the corridor's axis, like the CPU loop does
     est_s, _, _ = rp.run_slam(world, truth[:40], pipelined=False, scans=scans[:40])
     assert np.array_equal(est_s, est_g[:40])
+
+
+@pytest.mark.parametrize("variant", ["plain", "imu", "quirks+imu"])
+def test_slam_step_delivers_the_clouds_laser_mapping_run_publishes(oracle, variant):
+    """msfl_slam_config.keep_clouds.  LaserMapping::Run also rewrites cloud_full_res — UndistortScan while the
+    estimator is not initialised (laser_mapping.cc:170-176), DoUndistort once it is (:206) — accumulates it in the map frame
+    (TransformPointCloud by pose_map_scan2world_, :214-217) and publishes the sharp / flat clouds (:418-440).  70 scans with the
+    switch at scan 50, pipelined, against the oracle-driven loop: the full cloud in the scan frame and the index lists bit for bit,
+    the map-frame cloud as close as the two pose estimates (<= 1e-5 m, the poses themselves agree to ~1e-14), status_clouds 0;
+    poses equal a run without keep_clouds bit for bit (the extra launch changes nothing else)."""
+    quirks, with_imu = "quirks" in variant, "imu" in variant
+    n = 70
+    world = synth.World(ground_half=45.0)
+    truth = rp.trajectory(300)[:n]
+    imu = rp.synthetic_imu(truth, switch_at=50) if with_imu else None
+    co, cg = [], []
+    est_o, _ = rp.run(OracleBackendRigid3d(oracle), world, truth, quirks=quirks, imu=imu, clouds_out=co)
+    est_g, recs, _ = rp.run_slam(world, truth, pipelined=True, quirks=quirks, imu=imu, clouds_out=cg)
+    est_n, _, _ = rp.run_slam(world, truth, pipelined=True, quirks=quirks, imu=imu)
+    assert np.array_equal(est_g, est_n)
+    assert len(co) == len(cg) == n and all(r.status_clouds == 0 for r in recs)
+    moved = 0
+    for k in range(n):
+        a, b = cg[k], co[k]
+        for key in ("sharp", "less_sharp", "flat", "less_flat", "ring"):
+            assert np.array_equal(a[key], b[key]), (k, key)
+        assert np.array_equal(a["full_scan"], b["full_scan"]), k
+        assert a["full_map"].shape == b["full_map"].shape and np.abs(a["full_map"] - b["full_map"]).max() < 1e-5, k
+        assert np.array_equal(a["full_map"][:, 3], a["full_scan"][:, 3])            # intensity (the relative time) rides along
+        # the listed points of the full cloud are the clouds PublishScan publishes: after the IMU passes they differ from the raw scan
+        moved += int(np.any(a["full_scan"][:, :3] != rp_full(oracle, world, truth, k)[:, :3]))
+    assert moved == (n if with_imu else 0)
+    # the map-frame cloud really is pose_map applied to the scan-frame cloud (msfl_transform_cloud's arithmetic)
+    k = n - 1
+    want = oracle.transform_cloud(cg[k]["full_scan"], est_g[k])
+    assert np.array_equal(cg[k]["full_map"], want)
+
+
+def rp_full(oracle, world, truth, k):
+    """The raw extraction output of scan k (what cloud_full_res holds before any IMU pass)."""
+    key = (id(world), k)
+    if key not in rp_full.cache:
+        pts, ring = synth.make_scan(world, truth[k], synth.SEED + 5000 + k)
+        rp_full.cache[key] = oracle.extract_features(pts, ring)["full"]
+    return rp_full.cache[key]
+
+
+rp_full.cache = {}
+
+
+def test_clouds_are_refused_without_the_switch_and_after_the_buffers_moved_on():
+    from msf_loam_amd import capi
+    world = synth.World(ground_half=45.0)
+    truth = rp.trajectory(300)[:4]
+    scans = [synth.make_scan(world, truth[k], synth.SEED + 5000 + k) for k in range(4)]
+    plain = capi.Slam(0, max_scan_points=max(len(p) for p, _ in scans), max_rings=16, pose_odom2map=truth[0])
+    plain.add_scan(*scans[0])
+    with pytest.raises(capi.MsflError) as e:
+        plain.clouds(0)
+    assert e.value.status == capi.BAD_ARG and "keep_clouds" in str(e.value)
+    plain.close()
+    slam = capi.Slam(0, max_scan_points=max(len(p) for p, _ in scans), max_rings=16, pose_odom2map=truth[0], keep_clouds=1)
+    for k in range(3):
+        slam.add_scan(*scans[k])
+    assert len(slam.clouds(2)["full_scan"]) > 20000 and len(slam.clouds(1)["full_scan"]) > 20000
+    with pytest.raises(capi.MsflError) as e:
+        slam.clouds(0)                      # scan 2 reuses scan 0's buffer set
+    assert e.value.status == capi.BAD_ARG
+    # a time stamp outside the pre-integration span on a point that is in neither list: status_clouds, the point left alone
+    imu = rp.synthetic_imu(truth, switch_at=0)[3]
+    imu = dict(imu); imu["sum_dt"] = np.linspace(0.0, 0.099, 45)          # the last points of every ring (the margins) have t ~ 0.1
+    r = slam.add_scan(*scans[3], imu=imu)
+    if r.status_imu == 0:                    # the listed points all fit the span: then only the margins can be outside
+        assert r.status_clouds in (0, capi.BAD_ARG)
+    slam.close()
