@@ -139,6 +139,7 @@ struct msfl_handle_s {
   // not the error text, to run PCL's drop-the-non-finite-points path.
   int vox_nonfinite_cloud = -1;
   const float4* vox_staged_pts = nullptr;
+  bool voxel_no_big = false;              // MSFL_VOXEL_NO_BIG=1: lists beyond the LDS forms go straight to the device-wide form (A/B of the round-5 big form)
   bool voxel_force_global = false;        // MSFL_VOXEL_GLOBAL=1: the batched voxel filter keeps the device-wide radix-sort form (A/B testing)
   long long odom_wave_max_targets = -1;   // MSFL_ODOM_WAVE_MAX_TARGETS: previous-scan points up to which a small batch takes the one-wavefront-per-query kernel (default 4096 per pair)
   bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)
@@ -156,6 +157,9 @@ struct msfl_handle_s {
   DevBuf ex[16];
   DevBuf od[20];
   DevBuf vb[14];  // batched voxel filter
+  DevBuf fit_fallback;                    // two {count, record numbers} lists of the whole-batch fit kernel's deferred pivoted-QR planes
+  size_t fit_fallback_words = 0; int fit_fallback_parity = 0;
+  DevBuf vox_big_scratch, vox_big_list;   // the one-workgroup form for lists of 65 536 .. 131 071 points (round 5): per-workgroup run scratch, list of refused clouds
   DevBuf vb2[6];  // second scratch set of the pair form: staging, run sums, counts/flags/offsets, offsets
   DevBuf pp[5];   // per-point passes: pre-integration samples, staged points, dq, dp, flag
   DevBuf pr[5];   // batched (map, scan) pairs: map offsets and cell-table bases per cloud kind, preset status
@@ -312,6 +316,17 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi, 
   return MSFL_OK;
 }
 
+// the two fallback lists of the whole-batch fit kernel (msfl_kernels.cuh: fit_fallback_kernel), n_surf + 1 ints each, zeroed when (re)allocated
+msfl_status ensure_fit_fallback(msfl_handle* h, int n_surf) {
+  const size_t words = (size_t)std::max(n_surf, 0) + 1;
+  if (h->fit_fallback_words >= words) return MSFL_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));            // a launch in flight may still read the old lists
+  HIPCHK(h, h->fit_fallback.reserve(2 * words * sizeof(int)));
+  HIPCHK(h, hipMemsetAsync(h->fit_fallback.p, 0, 2 * words * sizeof(int), h->stream));
+  h->fit_fallback_words = words; h->fit_fallback_parity = 0;
+  return MSFL_OK;
+}
+
 // one data-association pass = kNN kernel + fit kernel
 // (records [rec_begin, rec_end) of the batch; rec_end < 0: all of them)
 // seed: `nn` still holds this batch's neighbours from the previous outer iteration (same records, same map index): the 5-NN search
@@ -395,9 +410,19 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
         // a whole large batch: corner and surf features through their own specialisations of the fit (msfl_kernels.cuh)
         const int n_c = n_rec - bv.n_surf_total, n_s = bv.n_surf_total;
         const int edge_blocks = div_up(n_c, kAssocBlock), plane_blocks = div_up(n_s, kAssocBlock);
+        // fallback lists (count + record numbers) of the deferred pivoted-QR fits: two, used alternately, each re-armed by the OTHER launch's
+        // fallback kernel (zeroed at allocation)
+        // (sized by ensure_fit_fallback in the callers, which can report an allocation failure)
+        int* fb = h->fit_fallback.as<int>() + (size_t)h->fit_fallback_parity * h->fit_fallback_words;
+        int* fb_next = h->fit_fallback.as<int>() + (size_t)(1 - h->fit_fallback_parity) * h->fit_fallback_words;
+        h->fit_fallback_parity ^= 1;
         hipLaunchKernelGGL(fit_scan2map_split_kernel, dim3(edge_blocks + plane_blocks), block, 0, st, bv, h->map_c.sorted.as<float4>(),
                            h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
-                           h->records.as<double>(), full, edge_blocks);
+                           h->records.as<double>(), full, edge_blocks, fb);
+#if MSFL_FIT_DEFER
+        hipLaunchKernelGGL(fit_fallback_kernel, dim3(64), dim3(64), 0, st, bv, h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.plane_tolerance,
+                           h->records.as<double>(), full, (const int*)fb, fb_next);
+#endif
       } else
       hipLaunchKernelGGL(fit_scan2map_kernel<false>, grid, block, 0, st, bv, h->map_c.sorted.as<float4>(),
                          h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
@@ -441,6 +466,7 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
     dv.pprime = h->pprime.as<double>();
   }
   const SolverParams sp = solver_params(h->prm, 0);
+  { const msfl_status fs = ensure_fit_fallback(h, bv.n_surf_total); if (fs) return fs; }
   for (int it = 0; it < h->prm.outer_iterations; it++) {
     if (it == 0 && (n_chunks > 1 || enqueue_chunk)) {
       for (int c = 0; c < n_chunks; c++) {
@@ -549,6 +575,7 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
   if (const char* e = std::getenv("MSFL_KNN_FORM")) h->knn_form = !std::strcmp(e, "lane") ? 1 : !std::strcmp(e, "rows") ? 2 : 0;
   if (const char* e = std::getenv("MSFL_ODOM_WAVE_MAX_TARGETS")) h->odom_wave_max_targets = std::atoll(e);
   if (const char* e = std::getenv("MSFL_VOXEL_GLOBAL")) h->voxel_force_global = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MSFL_VOXEL_NO_BIG")) h->voxel_no_big = std::atoi(e) != 0;
   *out = h;
   return MSFL_OK;
 }
@@ -589,6 +616,7 @@ void msfl_destroy(msfl_handle* h) {
   for (auto& b : h->pr) b.release();
   for (auto& b : h->vb) b.release();
   for (auto& b : h->vb2) b.release();
+  h->vox_big_scratch.release(); h->vox_big_list.release(); h->fit_fallback.release();
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -879,6 +907,7 @@ msfl_status msfl_associate_scan2map(msfl_handle* h, const msfl_point* corner, in
   s = stage_single(h, corner, n_corner, surf, n_surf, pose, bv); if (s) return s;
   DeskewView dv{};
   HIPCHK(h, h->pprime.reserve((size_t)n * 6 * sizeof(double)));   // {C,N} staging for the host-format output
+  s = ensure_fit_fallback(h, bv.n_surf_total); if (s) return s;
   s_launch_assoc(h, bv, h->poses.as<double>(), h->status.as<int>(), false, dv, n, h->pprime.as<double>());
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(records_out, h->pprime.p, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));

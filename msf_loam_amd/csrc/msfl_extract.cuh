@@ -918,15 +918,25 @@ constexpr int kVoxSmallPoints = 4096;
 // 4 096 per wavefront slice, can never overflow (a slice holds at most 4 096 points), so a cloud of up to 65 535 points
 // that the LDS forms refused for its RUN count (flag 4) is served without leaving the device: the per-scan SLAM step has
 // no host round trip in which it could fall back to the device-wide form.  only_escalated == 2: serve flag-4 clouds.
-template <int kVoxWaves, int kVoxRunsPerWave, bool kGlobal = false>
-__global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBatchView v, float4* __restrict__ staging, float4* __restrict__ run_sums,
-                                                                          int* __restrict__ m_out, int* __restrict__ flags, int only_escalated,
-                                                                          unsigned long long* __restrict__ g_run = nullptr,
-                                                                          unsigned short* __restrict__ g_ord = nullptr) {
+// kBig (fourth form, <16, 4096, true, true>, round 5): a list of up to 131 071 points (a 64-beam less-flat list is ~100 k) in ONE
+// workgroup with the records in global scratch: the run record packs 3 x 13 coordinate bits (+-4095 voxels) | 18 bits first point | 6 bits
+// length, the chunk table has two entries per thread.  65 536 run slots (run ids stay 16-bit); more runs, wider coordinates or more
+// points keep flag 4 and the batch goes to the device-wide form as before.  Launched persistently (voxel_cloud_big_kernel: a fixed
+// number of workgroups walk the list of refused clouds), so the scratch is per workgroup, not per cloud.
+template <int kVoxWaves, int kVoxRunsPerWave, bool kGlobal, bool kBig>
+__device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const int b, float4* __restrict__ staging, float4* __restrict__ run_sums,
+                                                 int* __restrict__ m_out, int* __restrict__ flags, int only_escalated,
+                                                 unsigned long long* __restrict__ g_run, unsigned short* __restrict__ g_ord) {
   constexpr int kVoxMaxRuns = kVoxWaves * kVoxRunsPerWave;
   constexpr int kThreads = 64 * kVoxWaves;
   constexpr int kLdsRuns = kGlobal ? 1 : kVoxMaxRuns;
-  __shared__ unsigned long long s_run_lds[kLdsRuns];          // [coords 3 x 14 bits, later the voxel index : 42][first point : 16][length - 1 : 6]
+  // run record: [coords 3 x kCB bits, later the voxel index][first point : kFB][length - 1 : 6]
+  constexpr int kCB = kBig ? 13 : 14, kFB = kBig ? 18 : 16, kCellShift = kFB + 6;
+  constexpr int kCoordOff = 1 << (kCB - 1);
+  constexpr unsigned long long kCoordMask = (1ull << kCB) - 1ull, kLowMask = (1ull << kCellShift) - 1ull, kFirstMask = (1ull << kFB) - 1ull;
+  constexpr int kMaxPoints = kBig ? 131071 : (kVoxWaves < 16 ? kVoxSmallPoints : kVoxMaxPoints);
+  static_assert(!kBig || kGlobal, "the big form keeps its records in global scratch");
+  __shared__ unsigned long long s_run_lds[kLdsRuns];          // (see the record layout above)
   __shared__ unsigned short s_ord_lds[2][kLdsRuns];
   unsigned long long* const s_run = kGlobal ? g_run + (size_t)blockIdx.x * kVoxMaxRuns : s_run_lds;
   unsigned short* const s_ord0 = kGlobal ? g_ord + (size_t)blockIdx.x * 2 * kVoxMaxRuns : s_ord_lds[0];
@@ -938,12 +948,11 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   // upper rings of an outdoor scan are canopy: nearly every point its own voxel, 900-1 000 runs in a 1 400-point slice while the
   // whole list has 8-10 k) no longer overflows a 768-slot slice and sends the batch to the device-wide form.  The chunk table
   // (first slot, runs) restores the arrival order for the sort: chunks in (wavefront, position) order, slots ascending inside.
-  constexpr int kMaxChunks = kVoxWaves * 64;                  // <= 65 535 (4 096) points over 16 (4) slices of whole chunks
+  constexpr int kMaxChunks = kVoxWaves * (kBig ? 128 : 64);  // <= 65 535 (4 096; big: 131 071) points over 16 (4) slices of whole chunks
   __shared__ unsigned short s_cbase[kMaxChunks], s_ccnt[kMaxChunks];
   __shared__ int s_alloc;
   __shared__ int s_bb[6];
   __shared__ int s_flag, s_total, s_wsum[kVoxWaves];
-  const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cap = v.off[b + 1] - v.off[b];
   const int n = v.count ? min(max(v.count[b], 0), cap) : cap;
@@ -953,7 +962,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   if (tid == 0) { s_flag = 0; s_alloc = 0; for (int a = 0; a < 3; a++) { s_bb[a] = INT32_MAX; s_bb[3 + a] = INT32_MIN; } }
   for (int c = tid; c < kMaxChunks; c += kThreads) s_ccnt[c] = 0;
   __syncthreads();
-  if (n > (kSmall ? kVoxSmallPoints : kVoxMaxPoints)) { if (tid == 0) { flags[b] = kSmall ? 5 : 4; m_out[b] = 0; } return; }
+  if (n > kMaxPoints) { if (tid == 0) { flags[b] = kSmall ? 5 : 4; m_out[b] = 0; } return; }
   // ---- phase 1 ----
   const int seg = ((n + kVoxWaves - 1) / kVoxWaves + 63) & ~63;       // points per wavefront, whole chunks
   const int k0 = wave * seg, k1 = min(k0 + seg, n);
@@ -990,7 +999,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
         const float4 p = pp[u];
         const float f0 = floorf(p.x * v.inv_leaf), f1 = floorf(p.y * v.inv_leaf), f2 = floorf(p.z * v.inv_leaf);
         if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) my_flag = max(my_flag, 3);
-        else if (!(fabsf(f0) < 8191.f && fabsf(f1) < 8191.f && fabsf(f2) < 8191.f)) my_flag = max(my_flag, 4);
+        else if (!(fabsf(f0) < (float)(kCoordOff - 1) && fabsf(f1) < (float)(kCoordOff - 1) && fabsf(f2) < (float)(kCoordOff - 1))) my_flag = max(my_flag, 4);
         c0 = (int)f0; c1 = (int)f1; c2 = (int)f2;
         mn[0] = min(mn[0], c0); mn[1] = min(mn[1], c1); mn[2] = min(mn[2], c2);
         mx[0] = max(mx[0], c0); mx[1] = max(mx[1], c1); mx[2] = max(mx[2], c2);
@@ -1015,8 +1024,8 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
         slot = cbase + __popcll(heads & ((1ull << lane) - 1ull));
         len = end - lane;
         if (slot < kVoxMaxRuns)
-          s_run[slot] = ((unsigned long long)(unsigned)(c0 + 8192) << 50) | ((unsigned long long)(unsigned)(c1 + 8192) << 36) |
-                        ((unsigned long long)(unsigned)(c2 + 8192) << 22) | ((unsigned long long)(unsigned)k << 6) |
+          s_run[slot] = ((unsigned long long)(unsigned)(c0 + kCoordOff) << (2 * kCB + kCellShift)) | ((unsigned long long)(unsigned)(c1 + kCoordOff) << (kCB + kCellShift)) |
+                        ((unsigned long long)(unsigned)(c2 + kCoordOff) << kCellShift) | ((unsigned long long)(unsigned)k << 6) |
                         (unsigned long long)(len - 1);
       }
       // The run's points summed in arrival order while they are in registers: head lane h adds the values of lanes
@@ -1062,16 +1071,20 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   const int E = s_alloc;                                   // all runs
   for (int id = tid; id < E; id += kThreads) {
     const unsigned long long r = s_run[id];
-    const long long i0 = (long long)((int)(r >> 50) & 0x3fff) - 8192 - mb0, i1 = (long long)((int)(r >> 36) & 0x3fff) - 8192 - mb1,
-                    i2 = (long long)((int)(r >> 22) & 0x3fff) - 8192 - mb2;
+    const long long i0 = (long long)(int)((r >> (2 * kCB + kCellShift)) & kCoordMask) - kCoordOff - mb0,
+                    i1 = (long long)(int)((r >> (kCB + kCellShift)) & kCoordMask) - kCoordOff - mb1,
+                    i2 = (long long)(int)((r >> kCellShift) & kCoordMask) - kCoordOff - mb2;
     const unsigned long long cell = (unsigned long long)(i0 + i1 * d0 + i2 * d0 * d1);
-    s_run[id] = (cell << 22) | (r & 0x3fffffull);
+    s_run[id] = (cell << kCellShift) | (r & kLowMask);
   }
   {
     // run ids in ARRIVAL order: exclusive prefix of the chunk table's counts (entry c owned by thread c; unused entries are 0), then every
     // wavefront lists the runs of its own chunks
-    static_assert(kMaxChunks <= kThreads, "one chunk-table entry per thread");
-    const int cnt = tid < kMaxChunks ? (int)s_ccnt[tid] : 0;
+    constexpr int kPer = kMaxChunks / kThreads > 0 ? kMaxChunks / kThreads : 1;      // chunk-table entries per thread (big form: 2)
+    static_assert(kMaxChunks <= kPer * kThreads, "the chunk table is covered by the workgroup");
+    int cnt_e[kPer], cnt = 0;
+#pragma unroll
+    for (int q = 0; q < kPer; q++) { const int e = kPer * tid + q; cnt_e[q] = e < kMaxChunks ? (int)s_ccnt[e] : 0; cnt += cnt_e[q]; }
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
@@ -1079,11 +1092,12 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
     __syncthreads();
     int excl = incl - cnt;
     for (int w = 0; w < wave; w++) excl += s_wsum[w];
-    // thread c now knows where chunk c's runs start in the arrival order; hand that to the wavefront that owns the chunk through
-    // the (now dead) count entry's neighbour array: s_hist is free until the sort
+    // thread t now knows where its chunks' runs start in the arrival order; handed to the wavefront that owns the chunk through the
+    // histogram area (free until the sort)
     int* const c_at = reinterpret_cast<int*>(&s_hist[0][0]);             // kMaxChunks ints <= kVoxWaves * 256 * 2 bytes
     static_assert(kMaxChunks * 4 <= kVoxWaves * 256 * 2, "chunk prefix fits the histogram area");
-    if (tid < kMaxChunks) c_at[tid] = excl;
+#pragma unroll
+    for (int q = 0; q < kPer; q++) { const int e = kPer * tid + q; if (e < kMaxChunks) c_at[e] = excl; excl += cnt_e[q]; }
     __syncthreads();
     const int n_chunks = (k1 > k0) ? ((k1 - k0 + 63) >> 6) : 0;
     for (int c = 0; c < n_chunks; c++) {
@@ -1105,7 +1119,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
     for (int base = e0; base < e1; base += 64) {
       const int pos = base + lane;
       const bool valid = pos < e1;
-      const unsigned dg = valid ? (unsigned)((s_run[s_ord(cur)[pos]] >> (22 + shift)) & 0xffu) : 0x100u;
+      const unsigned dg = valid ? (unsigned)((s_run[s_ord(cur)[pos]] >> (kCellShift + shift)) & 0xffu) : 0x100u;
       unsigned long long peers = __ballot(valid);
 #pragma unroll
       for (int bit = 0; bit < 8; bit++) { const unsigned long long m = __ballot((dg >> bit) & 1u); peers &= ((dg >> bit) & 1u) ? m : ~m; }
@@ -1132,7 +1146,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
       const int pos = base + lane;
       const bool valid = pos < e1;
       const unsigned short id = valid ? s_ord(cur)[pos] : (unsigned short)0;
-      const unsigned dg = valid ? (unsigned)((s_run[id] >> (22 + shift)) & 0xffu) : 0x100u;
+      const unsigned dg = valid ? (unsigned)((s_run[id] >> (kCellShift + shift)) & 0xffu) : 0x100u;
       unsigned long long peers = __ballot(valid);
 #pragma unroll
       for (int bit = 0; bit < 8; bit++) { const unsigned long long m = __ballot((dg >> bit) & 1u); peers &= ((dg >> bit) & 1u) ? m : ~m; }
@@ -1153,7 +1167,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
   for (int base = 0; base < E; base += kThreads) {
     const int pos = base + tid;
     bool head = false;
-    if (pos < E) head = pos == 0 || (s_run[s_ord(cur)[pos]] >> 22) != (s_run[s_ord(cur)[pos - 1]] >> 22);
+    if (pos < E) head = pos == 0 || (s_run[s_ord(cur)[pos]] >> kCellShift) != (s_run[s_ord(cur)[pos - 1]] >> kCellShift);
     const unsigned long long hm = __ballot(head);
     if (lane == 0) s_wsum[wave] = __popcll(hm);
     __syncthreads();
@@ -1193,7 +1207,7 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
     };
     for (int j = j0 + 1; j < j1; j++) {
       const unsigned long long rec = s_run[s_ord(cur)[j]];
-      const int k = (int)((rec >> 6) & 0xffffu), len = (int)(rec & 0x3fu) + 1;
+      const int k = (int)((rec >> 6) & kFirstMask), len = (int)(rec & 0x3fu) + 1;
       total += len;
       int src[4];
       resolve4(k, 0, len, src);
@@ -1255,13 +1269,13 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
     int total = (int)(s_run[id0] & 0x3fu) + 1;
     // software pipeline over the runs: the next run's points are loading while this one is summed
     unsigned long long rec = s_run[s_ord(cur)[j0 + 1]];
-    int k = (int)((rec >> 6) & 0xffffu), len = (int)(rec & 0x3fu) + 1;
+    int k = (int)((rec >> 6) & kFirstMask), len = (int)(rec & 0x3fu) + 1;
     float4 p = vb_point(v, b, k + min(lane, len - 1));
     for (int j = j0 + 1; j < j1; j++) {
       const float4 pc = p; const int lc = len;
       if (j + 1 < j1) {
         rec = s_run[s_ord(cur)[j + 1]];
-        k = (int)((rec >> 6) & 0xffffu); len = (int)(rec & 0x3fu) + 1;
+        k = (int)((rec >> 6) & kFirstMask); len = (int)(rec & 0x3fu) + 1;
         p = vb_point(v, b, k + min(lane, len - 1));
       }
       for (int e = 0; e < lc; e++) {
@@ -1272,6 +1286,26 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
     if (lane == 0) { const float c = (float)total; out[r] = make_float4(sx / c, sy / c, sz / c, st / c); }
   }
   if (tid == 0) { flags[b] = 0; m_out[b] = m; }
+}
+
+template <int kVoxWaves, int kVoxRunsPerWave, bool kGlobal = false>
+__global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBatchView v, float4* __restrict__ staging, float4* __restrict__ run_sums,
+                                                                          int* __restrict__ m_out, int* __restrict__ flags, int only_escalated,
+                                                                          unsigned long long* __restrict__ g_run = nullptr,
+                                                                          unsigned short* __restrict__ g_ord = nullptr) {
+  voxel_cloud_body<kVoxWaves, kVoxRunsPerWave, kGlobal, false>(v, (int)blockIdx.x, staging, run_sums, m_out, flags, only_escalated, g_run, g_ord);
+}
+
+// The big form, persistent: gridDim.x workgroups (each with its own 65 536-run scratch) walk the list of clouds the LDS forms refused
+// (flag 4); a cloud the big form cannot hold either keeps its flag.
+constexpr size_t kVoxBigScratchBytes = (size_t)65536 * 8 + (size_t)2 * 65536 * 2;     // per workgroup: run records + two order buffers
+__global__ void __launch_bounds__(1024) voxel_cloud_big_kernel(VoxelBatchView v, float4* __restrict__ staging, float4* __restrict__ run_sums,
+                                                                int* __restrict__ m_out, int* __restrict__ flags, const int* __restrict__ cloud_list,
+                                                                int n_list, unsigned long long* __restrict__ g_run, unsigned short* __restrict__ g_ord) {
+  for (int j = (int)blockIdx.x; j < n_list; j += (int)gridDim.x) {
+    voxel_cloud_body<16, 4096, true, true>(v, cloud_list[j], staging, run_sums, m_out, flags, 2, g_run, g_ord);
+    __syncthreads();                       // the next cloud re-arms the shared state
+  }
 }
 
 // staging (cloud b's centroids at off[b]) -> the clouds back to back: out[out_off[b] + r]

@@ -608,7 +608,11 @@ __device__ __forceinline__ FitOut edge_fit(const float4 (&nb)[5], double ratio) 
 #ifndef MSFL_PLANE_ADJ
 #define MSFL_PLANE_ADJ 1            /* 0: the unpivoted-QR fast path of round 3 instead of the centred adjugate form (A/B) */
 #endif
-__device__ __forceinline__ FitOut plane_fit(const float4 (&nb)[5], double tol) {
+// DEFER (round 5, the whole-batch fit kernel): an ill-conditioned neighbourhood does not run the pivoted QR here but is reported through
+// `deferred` and fitted by fit_fallback_kernel; with the fallback out of this binary the hot path needs fewer registers (more
+// wavefronts per SIMD).  The result is the same function of the five points either way.
+template <bool DEFER = false>
+__device__ __forceinline__ FitOut plane_fit(const float4 (&nb)[5], double tol, bool* deferred = nullptr) {
   FitOut o; o.ok = false; o.C = mk3(0, 0, 0); o.N = mk3(0, 0, 0);
   d3 c = mk3(0, 0, 0);
 #pragma unroll
@@ -631,7 +635,8 @@ __device__ __forceinline__ FitOut plane_fit(const float4 (&nb)[5], double tol) {
     if (!MSFL_IEEE_DIV) x = lstsq5x3_fast(A, b, well);             // overwrites A, b
   }
 #endif
-  if (!well) {                                     // ill-conditioned or rank-deficient: the reference's pivoted QR decides
+  if (DEFER && !well) { *deferred = true; return o; }
+  if (!DEFER && !well) {                           // ill-conditioned or rank-deficient: the reference's pivoted QR decides
     double A[5][3], b[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) { A[j][0] = (double)nb[j].x; A[j][1] = (double)nb[j].y; A[j][2] = (double)nb[j].z; b[j] = -1.0; }
@@ -985,10 +990,10 @@ knn5_scan2map_rows_kernel(BatchView bv, const double* __restrict__ poses, const 
 #endif
 // KIND 0: every record of [rec_begin, n_records) (one thread each, edges and planes as they come); KIND 1 / 2: the launch covers
 // the batch's corner / surf features only (thread = feature index in its cloud), so that the compiler sees one of the two fits.
-template <bool DESKEW, int KIND>
+template <bool DESKEW, int KIND, bool DEFER = false>
 __device__ __forceinline__ void fit_one(const BatchView& bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
                                         const int* __restrict__ nn, double line_ratio, double plane_tol, const DeskewView& dv,
-                                        double* __restrict__ rec, double* __restrict__ full, int block) {
+                                        double* __restrict__ rec, double* __restrict__ full, int block, int* __restrict__ fallback = nullptr) {
   int g, b, local, nc;
   if (KIND == 0) {
     g = bv.rec_begin + block * blockDim.x + threadIdx.x;
@@ -1015,7 +1020,12 @@ __device__ __forceinline__ void fit_one(const BatchView& bv, const float4* __res
   const bool have = p0 >= 0;                                  // no match: the other four slots were never written
   const float4 nb[5] = {mp[have ? p0 : 0], mp[have ? p1 : 0], mp[have ? p2 : 0], mp[have ? p3 : 0], mp[have ? p4 : 0]};
   if (p0 >= 0) {
-    fo = is_edge ? edge_fit(nb, line_ratio) : plane_fit(nb, plane_tol);
+    bool deferred = false;
+    fo = is_edge ? edge_fit(nb, line_ratio) : plane_fit<DEFER>(nb, plane_tol, &deferred);
+    if (DEFER && deferred) {                                    // fallback[0]: count, then the global record numbers; the record written
+      const int at = atomicAdd(fallback, 1);                    // below (rejected) is overwritten by fit_fallback_kernel
+      fallback[1 + at] = g;
+    }
     if (DESKEW && fo.ok) {
       // C' = C - (Vi dt - G dt^2/2): the velocity block is constant (mapping_scan_matcher.cc:94)
       const int fi = is_edge ? bv.corner_off[b] + local : bv.surf_off[b] + (local - nc);
@@ -1051,12 +1061,39 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
 // through its own specialisation of the body, at four wavefronts per SIMD (the plane fit alone needs 131 registers, the
 // mixed body 135: three wavefronts).  The edge blocks come first so that their longer per-record chain (the Jacobi
 // eigen-solver) runs under the plane blocks instead of forming the launch's tail.
-__global__ void __launch_bounds__(kAssocBlock, 4)
+#ifndef MSFL_FIT_DEFER
+#define MSFL_FIT_DEFER 1            /* 0: the pivoted-QR fallback inline in the whole-batch fit kernel, as in rounds 3-4 (A/B) */
+#endif
+#ifndef MSFL_FIT_SPLIT_WAVES
+#define MSFL_FIT_SPLIT_WAVES (MSFL_FIT_DEFER ? 5 : 4)
+#endif
+__global__ void __launch_bounds__(kAssocBlock, MSFL_FIT_SPLIT_WAVES)
 fit_scan2map_split_kernel(BatchView bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
                           const int* __restrict__ nn, double line_ratio, double plane_tol, DeskewView dv,
-                          double* __restrict__ rec, double* __restrict__ full, int edge_blocks) {
+                          double* __restrict__ rec, double* __restrict__ full, int edge_blocks, int* __restrict__ fallback) {
   if ((int)blockIdx.x < edge_blocks) fit_one<false, 1>(bv, map_c, map_s, nn, line_ratio, plane_tol, dv, rec, full, (int)blockIdx.x);
-  else fit_one<false, 2>(bv, map_c, map_s, nn, line_ratio, plane_tol, dv, rec, full, (int)blockIdx.x - edge_blocks);
+  else fit_one<false, 2, MSFL_FIT_DEFER != 0>(bv, map_c, map_s, nn, line_ratio, plane_tol, dv, rec, full, (int)blockIdx.x - edge_blocks, fallback);
+}
+// The planes whose neighbourhood failed the guards of plane_normal_centred (rank-deficient or ill-conditioned: a handful per million on
+// scanned surfaces): the reference's pivoted QR (plane_fit's non-deferred body), one thread each over a fixed small grid, the count
+// read on the device.  Re-arms the OTHER counter of the ping-pong pair for the next launch (this one is still being read).
+__global__ void __launch_bounds__(64)
+fit_fallback_kernel(BatchView bv, const float4* __restrict__ map_s, const int* __restrict__ nn, double plane_tol,
+                    double* __restrict__ rec, double* __restrict__ full, const int* __restrict__ fallback, int* __restrict__ next_counter) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0;
+  const int n = fallback[0];
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int g = fallback[1 + e];
+    const int b = find_scan(bv.rec_off, bv.n_scans, g);
+    const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
+    const int local = g - bv.rec_off[b];
+    const int* in = nn + 5 * (size_t)g;
+    const float4 nb[5] = {map_s[in[0]], map_s[in[1]], map_s[in[2]], map_s[in[3]], map_s[in[4]]};
+    const FitOut fo = plane_fit<false>(nb, plane_tol);
+    double* out = rec + plane_rec_off(bv, bv.surf_off[b] + (local - nc));
+    out[0] = fo.N.x; out[1] = fo.N.y; out[2] = fo.N.z; out[3] = dot(fo.N, fo.C);
+    if (full) { double* o = full + 6 * (size_t)g; o[0] = fo.C.x; o[1] = fo.C.y; o[2] = fo.C.z; o[3] = fo.N.x; o[4] = fo.N.y; o[5] = fo.N.z; }
+  }
 }
 
 // {C, N} x n_records (host/debug format) -> compact internal records

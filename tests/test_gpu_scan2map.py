@@ -643,3 +643,49 @@ def test_other_worlds_follow_the_oracle(gpu, oracle, kind):
             assert s == 0 and np.array_equal(p, singles[b])
     finally:
         h.close()
+
+
+def test_deferred_pivoted_qr_planes_equal_the_inline_fallback(gpu, oracle):
+    """Round 5: the whole-batch fit kernel (batches of >= 65 536 features) no longer carries the pivoted-QR fallback of the plane fit; a
+    neighbourhood that fails the guards of the adjugate form (planes through the origin: A n = -1 has no solution; collinear
+    neighbours; a plane seen from 1 km away) goes to a list and is fitted by fit_fallback_kernel.  120 copies of a job that is FULL of
+    such neighbourhoods, against the single-call path (which keeps the fallback inline) bit for bit, and the oracle's accept sets."""
+    rng = np.random.default_rng(61)
+    g_ = np.arange(-6, 7, dtype=np.float32) * 0.5
+    X, Y = np.meshgrid(g_, g_, indexing="ij")
+    origin_plane = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size, np.float32)], 1)                  # z = 0: through the origin
+    tilted = np.stack([X.ravel() + 20, Y.ravel(), 0.3 * (X.ravel() + 20) - 0.2 * Y.ravel()], 1)         # another plane through the origin
+    far = np.stack([X.ravel() + 1000.0, Y.ravel() + 1000.0, np.full(X.size, 2.0, np.float32)], 1)       # |c| >> spread: the grazing guard
+    line = np.stack([np.arange(40, dtype=np.float32) * 0.25 - 5, np.full(40, 40.0, np.float32), np.full(40, 1.0, np.float32)], 1)   # collinear: rank 1 after centring
+    ok_plane = np.stack([X.ravel() - 20, Y.ravel(), np.full(X.size, -1.5, np.float32)], 1)
+    ms = np.concatenate([origin_plane, tilted, far, line, ok_plane]).astype(np.float32)
+    ms = np.concatenate([ms + rng.normal(0, 1e-4, ms.shape).astype(np.float32) * (np.arange(len(ms)) % 3 == 0)[:, None], np.zeros((len(ms), 1), np.float32)], 1).astype(np.float32)
+    ms = ms[rng.permutation(len(ms))]
+    pole = np.stack([np.zeros(60, np.float32), np.zeros(60, np.float32) + 60, np.arange(60, dtype=np.float32) * 0.125], 1)
+    mc = np.concatenate([pole, np.zeros((60, 1), np.float32)], 1).astype(np.float32)
+    def around(p, n):
+        return p[rng.integers(0, len(p), n)] + rng.uniform(-0.2, 0.2, (n, 3)).astype(np.float32)
+    q = np.concatenate([around(origin_plane, 150), around(tilted, 150), around(far, 120), around(line, 60), around(ok_plane, 120)]).astype(np.float32)
+    surf = np.concatenate([q, np.zeros((len(q), 1), np.float32)], 1).astype(np.float32)
+    corner = np.concatenate([pole[::3] + np.float32(0.05), np.zeros((20, 1), np.float32)], 1).astype(np.float32)
+    gpu.set_map(mc, ms)
+    poses = [np.array([0, 0, 0, 0, 0, 0, 1.0]), np.array([0.05, -0.02, 0.01, 0, 0, 0.001, 1.0]), np.array([-0.03, 0.04, 0.0, 0.001, 0, 0, 1.0])]
+    poses = [p / np.r_[1, 1, 1, [np.linalg.norm(p[3:])] * 4] for p in poses]
+    n_acc = 0
+    for pose in poses:
+        rec = gpu.associate_scan2map(corner, surf, pose)
+        corr = oracle.associate_scan2map(mc, ms, corner, surf, pose)
+        assert np.array_equal(np.any(rec[:, 3:] != 0, axis=1), corr["kind"] != 0)
+        n_acc += int((corr["kind"] != 0).sum())
+    assert n_acc > 300
+    B = 120
+    guesses = np.array([poses[i % 3] for i in range(B)])
+    co = np.arange(B + 1, dtype=np.int32) * len(corner); so = np.arange(B + 1, dtype=np.int32) * len(surf)
+    assert co[-1] + so[-1] >= 65536
+    for rep in range(3):                             # the two fallback lists alternate: three batches use both and re-arm both
+        pb, sb, ib = gpu.match_scan2map_batch(np.tile(corner, (B, 1)), co, np.tile(surf, (B, 1)), so, guesses, want_info=True)
+        for i in range(3):
+            s1, p1, i1 = gpu.match_scan2map(corner, surf, poses[i])
+            for j in range(i, B, 3):
+                assert sb[j] == s1 and np.array_equal(pb[j], p1), (rep, i, j)
+                assert list(ib[j].n_plane) == list(i1.n_plane) and list(ib[j].final_cost) == list(i1.final_cost)
