@@ -414,7 +414,7 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
         // fallback kernel (zeroed at allocation)
         // (sized by ensure_fit_fallback in the callers, which can report an allocation failure)
         int* fb = h->fit_fallback.as<int>() + (size_t)h->fit_fallback_parity * h->fit_fallback_words;
-        int* fb_next = h->fit_fallback.as<int>() + (size_t)(1 - h->fit_fallback_parity) * h->fit_fallback_words;
+        int* fb_next = h->fit_fallback.as<int>() + (size_t)(1 - h->fit_fallback_parity) * h->fit_fallback_words; (void)fb_next;
         h->fit_fallback_parity ^= 1;
         hipLaunchKernelGGL(fit_scan2map_split_kernel, dim3(edge_blocks + plane_blocks), block, 0, st, bv, h->map_c.sorted.as<float4>(),
                            h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,

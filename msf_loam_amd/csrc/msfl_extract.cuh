@@ -1278,8 +1278,10 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
         k = (int)((rec >> 6) & kFirstMask); len = (int)(rec & 0x3fu) + 1;
         p = vb_point(v, b, k + min(lane, len - 1));
       }
+      // e is wave-uniform: v_readlane (a scalar broadcast) instead of ds_bpermute; the additions are the same sequential f32 chain
       for (int e = 0; e < lc; e++) {
-        sx += __shfl(pc.x, e); sy += __shfl(pc.y, e); sz += __shfl(pc.z, e); st += __shfl(pc.w, e);
+        sx += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.x), e)); sy += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.y), e));
+        sz += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.z), e)); st += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.w), e));
       }
       total += lc;
     }
@@ -1299,7 +1301,10 @@ __global__ void __launch_bounds__(64 * kVoxWaves) voxel_cloud_lds_kernel(VoxelBa
 // The big form, persistent: gridDim.x workgroups (each with its own 65 536-run scratch) walk the list of clouds the LDS forms refused
 // (flag 4); a cloud the big form cannot hold either keeps its flag.
 constexpr size_t kVoxBigScratchBytes = (size_t)65536 * 8 + (size_t)2 * 65536 * 2;     // per workgroup: run records + two order buffers
-__global__ void __launch_bounds__(1024) voxel_cloud_big_kernel(VoxelBatchView v, float4* __restrict__ staging, float4* __restrict__ run_sums,
+#ifndef MSFL_VOX_BIG_WAVES
+#define MSFL_VOX_BIG_WAVES 8        /* waves per SIMD the big form is compiled for: 8 = two 1 024-thread workgroups per CU (64 VGPRs) */
+#endif
+__global__ void __launch_bounds__(1024, MSFL_VOX_BIG_WAVES) voxel_cloud_big_kernel(VoxelBatchView v, float4* __restrict__ staging, float4* __restrict__ run_sums,
                                                                 int* __restrict__ m_out, int* __restrict__ flags, const int* __restrict__ cloud_list,
                                                                 int n_list, unsigned long long* __restrict__ g_run, unsigned short* __restrict__ g_ord) {
   for (int j = (int)blockIdx.x; j < n_list; j += (int)gridDim.x) {

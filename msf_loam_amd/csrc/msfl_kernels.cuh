@@ -1062,7 +1062,9 @@ fit_scan2map_kernel(BatchView bv, const float4* __restrict__ map_c, const float4
 // mixed body 135: three wavefronts).  The edge blocks come first so that their longer per-record chain (the Jacobi
 // eigen-solver) runs under the plane blocks instead of forming the launch's tail.
 #ifndef MSFL_FIT_DEFER
-#define MSFL_FIT_DEFER 1            /* 0: the pivoted-QR fallback inline in the whole-batch fit kernel, as in rounds 3-4 (A/B) */
+#define MSFL_FIT_DEFER 0            /* 1: the pivoted-QR fallback of the whole-batch fit kernel deferred to fit_fallback_kernel (round 5: the hot kernel
+                                       drops to 92 VGPRs / 5 waves per SIMD and 0.098 ms, but the extra launch costs what it saves: 0.1063 vs 0.1045 ms
+                                       per pass for both; docs/rejected_experiments.md).  `make defer` builds it; the test of the path runs on either. */
 #endif
 #ifndef MSFL_FIT_SPLIT_WAVES
 #define MSFL_FIT_SPLIT_WAVES (MSFL_FIT_DEFER ? 5 : 4)
