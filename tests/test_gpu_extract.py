@@ -427,3 +427,65 @@ def test_voxel_pair_call_equals_the_two_batch_calls(gpu, oracle):
     # list a alone above the limit (its fallback used to overwrite list b's pending read-back), then both lists
     run(feats, extra_a=big)
     run(feats, extra_b=big, extra_a=big[:66000])
+
+
+def _sweep_cloud(rng, n, extent=25.0, step=0.008, jitter=0.004):
+    """n points along a random polyline of sweeps (runs of consecutive same-voxel points, voxels revisited by later sweeps)."""
+    parts, left = [], n
+    while left > 0:
+        m = min(left, int(rng.integers(400, 6000)))
+        d = rng.normal(size=3); d[2] *= 0.2; d /= np.linalg.norm(d)
+        start = rng.uniform(-extent, extent, 3) * [1, 1, 0.1]
+        parts.append(start[None, :] + (np.arange(m) * step)[:, None] * d[None, :] + rng.normal(0, jitter, (m, 3)))
+        left -= m
+    c = np.zeros((n, 4), np.float32)
+    c[:, :3] = np.concatenate(parts)
+    c[:, 3] = rng.uniform(0, 0.1, n)
+    return c
+
+
+def test_voxel_lists_beyond_the_lds_forms_and_pooled_run_slots(oracle, monkeypatch):
+    """Round 5.  (i) The run slots of the LDS form are one pool per cloud: a list whose runs crowd into one wavefront's slice (the canopy
+    rings of an outdoor scan) fits as long as the cloud's total does.  (ii) Lists of 65 536 .. 131 071 points (a 64-beam less-flat list)
+    take the big one-workgroup form (records in global scratch, 13-bit coordinates), with the device-wide form behind it for what that
+    cannot hold either: more than 131 071 points, more than 65 536 runs, coordinates beyond +-4 095 voxels.  Every path equals the oracle
+    bit for bit, and the three forms equal each other (MSFL_VOXEL_NO_BIG / MSFL_VOXEL_GLOBAL handles)."""
+    from msf_loam_amd import capi
+    rng = np.random.default_rng(91)
+    # (i) 20 000 points: 18 000 along one slow sweep (few runs), then 2 000 scattered ones (2 000 runs in the last slice of ~1 300 points)
+    crowd = np.concatenate([_sweep_cloud(rng, 18000, step=0.004), np.zeros((2000, 4), np.float32)])
+    crowd[18000:, :3] = rng.uniform(-25, 25, (2000, 3))
+    big_a = _sweep_cloud(rng, 100_000)                         # ~100 k points, long runs: the big form
+    big_b = _sweep_cloud(rng, 131_071)                         # its largest size
+    over = _sweep_cloud(rng, 131_072)                          # one more: device-wide
+    many = np.zeros((90_000, 4), np.float32); many[:, :3] = rng.uniform(-40, 40, (90_000, 3))    # 90 000 runs of length 1 (> 65 536 slots)
+    wide = _sweep_cloud(rng, 70_000, extent=4.0, step=0.002); wide[:100, 0] += 1500.0   # 7 500 voxels from the rest at 0.2 m: beyond the big form's +-4 095
+    small = _sweep_cloud(rng, 3000)
+    empty = np.zeros((0, 4), np.float32)
+    cases = [([crowd], 0.4), ([crowd, small], 0.2), ([big_a], 0.4), ([small, big_a, empty, big_b], 0.4), ([big_b], 0.2), ([over, small], 0.4),
+             ([many, small], 0.4), ([wide, small], 0.2), ([big_a, many, crowd], 0.4)]
+    hs = {}
+    hs["default"] = capi.Handle(0)
+    monkeypatch.setenv("MSFL_VOXEL_NO_BIG", "1"); hs["no_big"] = capi.Handle(0); monkeypatch.delenv("MSFL_VOXEL_NO_BIG")
+    monkeypatch.setenv("MSFL_VOXEL_GLOBAL", "1"); hs["global"] = capi.Handle(0); monkeypatch.delenv("MSFL_VOXEL_GLOBAL")
+    try:
+        for clouds, leaf in cases:
+            off = np.cumsum([0] + [len(c) for c in clouds]).astype(np.int32)
+            outs = {k: h.voxel_downsample_batch(np.concatenate(clouds), off, leaf) for k, h in hs.items()}
+            for b, c in enumerate(clouds):
+                ref = oracle.voxel_grid(c, leaf) if len(c) else np.zeros((0, 4), np.float32)
+                for k, (out, out_off) in outs.items():
+                    assert np.array_equal(out[out_off[b]:out_off[b + 1]], ref), (k, leaf, b, len(c))
+        # through the index-list form the pipeline uses (device-resident counts), big list next to a small one
+        clouds = [big_a, small]
+        off = np.cumsum([0] + [len(c) + 17 for c in clouds]).astype(np.int32)
+        full = np.zeros((off[-1], 4), np.float32); idx = np.zeros(off[-1], np.int32); cnt = np.array([len(c) for c in clouds], np.int32)
+        for b, c in enumerate(clouds):
+            perm = rng.permutation(len(c) + 17)[:len(c)]
+            full[off[b] + perm] = c; idx[off[b]:off[b] + len(c)] = perm
+        out, out_off = hs["default"].voxel_downsample_batch(full, off, 0.4, idx=idx, count=cnt)
+        for b, c in enumerate(clouds):
+            assert np.array_equal(out[out_off[b]:out_off[b + 1]], oracle.voxel_grid(c, 0.4)), b
+    finally:
+        for h in hs.values():
+            h.close()
