@@ -9,7 +9,7 @@
   pairs                       `msfl_match_pairs_batch`: 256 (map, scan) pairs with 256 different ~34 k-point maps
 
 Checker use only: the oracle module is handed in by bench.py for the spot-checks; this file never imports it.
-Stand-alone on the GPU box (timings only):  python tools/bench_worlds.py [worlds|shares|all] [scans]
+Stand-alone on the GPU box (timings only):  python tools/bench_worlds.py [worlds|shares|all] [scans] [outdoor,corridor]
 """
 import json
 import os
@@ -230,7 +230,8 @@ if __name__ == "__main__":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     res = {}
     if what in ("worlds", "all"):
-        res["worlds"] = measure_worlds(scans=n)
+        kinds = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("outdoor", "corridor")
+        res["worlds"] = measure_worlds(scans=n, kinds=kinds)
     if what in ("shares", "all"):
         res.update(measure_shares())
     print(json.dumps(res))
