@@ -153,3 +153,30 @@ def test_config4_per_gpu_share_625_scans_vs_2m_point_map(gpu, oracle):
     poses = synth.random_poses(125, synth.SEED + 2500)
     scans = [synth.make_scan(w, poses[i], synth.SEED + 2501 + i) + (poses[i],) for i in range(125)]
     _share_properties(gpu, oracle, scans, 5, w, mc, ms, "configs[4] share")
+
+
+def test_64_beam_scan_in_the_outdoor_world(gpu, oracle):
+    """Round 5: configs[3]'s scan shape (64 beams, ~110 k points) in the world that is not the room: relief, building faces, trunks and
+    volumetric canopy.  Extraction bit for bit; the less-flat list (~95 k points, tens of thousands of runs) goes through the voxel
+    filter's big one-workgroup form or, beyond its 65 536 run slots, the device-wide chain — either way equal to pcl's filter as the
+    oracle restates it; the registration against the 677 k-point map follows the oracle (counts exact, pose <= 1e-7)."""
+    w, mc, ms = common.other_world("outdoor")
+    pose = synth.world_poses(w, 1, synth.SEED + 64)[0]
+    pts, ring = synth.make_scan(w, pose, synth.SEED + 65, n_beams=64, n_az=1900, elev=(-24.8, 2.0))
+    assert len(pts) > 80000 and ring.max() == 63
+    f, fo = gpu.extract_features(pts, ring), oracle.extract_features(pts, ring)
+    for k in ("sharp", "less_sharp", "flat", "less_flat", "curvature", "label", "ring"):
+        assert np.array_equal(f[k], fo[k]), k
+    lf = f["full"][f["less_flat"]]
+    assert len(lf) > 65535                                       # beyond the LDS forms
+    corner, surf = gpu.voxel_downsample(f["full"][f["less_sharp"]], 0.2), gpu.voxel_downsample(lf, 0.4)
+    assert np.array_equal(corner, oracle.voxel_grid(fo["full"][fo["less_sharp"]], 0.2))
+    assert np.array_equal(surf, oracle.voxel_grid(fo["full"][fo["less_flat"]], 0.4))
+    gpu.set_map(mc, ms)
+    guess = synth.perturb_pose(pose, np.random.default_rng(64))
+    s, pg, ig = gpu.match_scan2map(corner, surf, guess)
+    rc, po, io = oracle.match_scan2map(mc, ms, corner, surf, guess)
+    assert s == rc == 0 and list(ig.n_plane) == list(io.n_plane) and list(ig.n_edge) == list(io.n_edge)
+    assert list(ig.lm_iterations) == list(io.lm_iterations)
+    dt, dr = synth.pose_error(pg, po)
+    assert dt < 1e-7 and dr < 1e-7
