@@ -189,6 +189,27 @@ def run(backend, world, poses_true, verbose=False, maps_out=None, scans=None, qu
     return np.array(est), {k: 1e3 * v / m for k, v in t_stage.items()}
 
 
+def world_drive(world, kind, n):
+    """A drive through the outdoor / corridor world (~0.4 m and a degree or two per scan): down the x = 0 street following the relief, or
+    down the corridor's axis (the same drives as tests/common.py:world_drive; wraps around after ~125 scans so that any length stays inside)."""
+    poses = []
+    for k in range(n):
+        if kind == "outdoor":
+            kk = k % 250
+            kk = kk if kk < 125 else 250 - kk                        # there and back again
+            y = -25.0 + 0.4 * kk
+            x = 1.2 * np.sin(0.11 * kk)
+            yaw = np.pi / 2 - np.arctan(1.2 * 0.11 * np.cos(0.11 * kk) / 0.4) * 0.5
+            z = float(world.geom.ground(x, y)) + 1.8 + 0.02 * np.sin(0.5 * kk)
+            poses.append(np.r_[x, y, z, synth.quat_from_euler(0.015 * np.sin(0.3 * kk), 0.01 * np.cos(0.2 * kk), yaw)])
+        else:
+            kk = k % 250
+            kk = kk if kk < 125 else 250 - kk
+            poses.append(np.r_[-20.0 + 0.4 * kk, 0.3 * np.sin(0.15 * kk), 1.5 + 0.02 * np.sin(0.4 * kk),
+                               synth.quat_from_euler(0.01 * np.sin(0.3 * kk), 0.01 * np.cos(0.25 * kk), 0.05 * np.sin(0.2 * kk))])
+    return np.array(poses)
+
+
 def run_slam(world, poses_true, pipelined=False, device=0, scans=None, verbose=False, maps_out=None, quirks=False, imu=None, clouds_out=None):
     """The same loop through the device-resident SLAM step (msfl_slam_add_scan): raw scan in, pose out, one
     synchronisation per scan (pipelined=False) or none until the record is fetched one scan later (pipelined=True: the
@@ -246,9 +267,16 @@ def main():
     ap.add_argument("--dump-poses", default=None, help="write the estimated map poses (n x 7 float64, .npy) here")
     ap.add_argument("--reference-quirks", action="store_true", help="msfl_slam_config.reference_quirks = 1 (surf list truncation of the reference)")
     ap.add_argument("--imu", action="store_true", help="feed a synthetic pre-integration with every scan (UndistortScan, then the is_initialized branch from scan 50)")
+    ap.add_argument("--world", choices=["room", "outdoor", "corridor"], default="room",
+                    help="room: the SURVEY 8d world and its loop; outdoor / corridor: msf_loam_amd/worlds.py with a drive down the street / the axis (round 5)")
+    ap.add_argument("--keep-clouds", action="store_true", help="msfl_slam_config.keep_clouds = 1 and fetch every scan's clouds (what PublishScan would publish)")
     args = ap.parse_args()
-    world = synth.World(ground_half=45.0)
-    truth = trajectory(args.scans)
+    if args.world == "room":
+        world = synth.World(ground_half=45.0)
+        truth = trajectory(args.scans)
+    else:
+        world = synth.World(kind=args.world)
+        truth = world_drive(world, args.world, args.scans)
     if args.mode == "staged":
         est, ms = run(GpuBackend(0), world, truth, verbose=True)
         print(json.dumps({"mode": "staged", "scans": args.scans, "ate_rmse_m": ate(est, truth),
@@ -259,11 +287,11 @@ def main():
     import gc
     gc.collect(); gc.disable()
     est, recs, ms = run_slam(world, truth, pipelined=args.mode == "slam-pipelined", scans=scans, quirks=args.reference_quirks,
-                             imu=synthetic_imu(truth) if args.imu else None)
+                             imu=synthetic_imu(truth) if args.imu else None, clouds_out=[] if args.keep_clouds else None)
     last = recs[-1]
     if args.dump_poses:
         np.save(args.dump_poses, est)
-    print(json.dumps({"mode": args.mode, "scans": args.scans, "reference_quirks": bool(args.reference_quirks), "imu": bool(args.imu),
+    print(json.dumps({"mode": args.mode, "world": args.world, "keep_clouds": bool(args.keep_clouds), "scans": args.scans, "reference_quirks": bool(args.reference_quirks), "imu": bool(args.imu),
                       "ate_rmse_m": ate(est, truth),
                       "final_error_m_rad": synth.pose_error(est[-1], truth[-1]), "ms_per_scan_end_to_end": ms,
                       "scans_per_s": 1e3 / ms if ms else None,

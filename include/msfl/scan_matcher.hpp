@@ -321,11 +321,12 @@ class LaserSlam {
   };
 
   // reference_quirks: FilterLessFlatLessCornerFeature as the reference executes it (laser_mapping.cc:340-364), see msfl_slam_config
+  // keep_clouds: also produce what LaserMapping::Run publishes / accumulates (cloud_full_res after the IMU passes, its map-frame copy), see Clouds()
   explicit LaserSlam(int device = 0, int max_scan_points = 200000, int max_rings = 128, const Rigid3d& pose_odom2map = Rigid3d::Identity(),
-                     bool reference_quirks = false) {
+                     bool reference_quirks = false, bool keep_clouds = false) : max_scan_points_(max_scan_points) {
     msfl_slam_config c;
     msfl_slam_default_config(&c);
-    c.max_scan_points = max_scan_points; c.max_rings = max_rings; c.reference_quirks = reference_quirks ? 1 : 0;
+    c.max_scan_points = max_scan_points; c.max_rings = max_rings; c.reference_quirks = reference_quirks ? 1 : 0; c.keep_clouds = keep_clouds ? 1 : 0;
     const auto v = pose_odom2map.ToVector7();
     for (int k = 0; k < 7; ++k) c.pose_odom2map[k] = v[k];
     const msfl_status st = msfl_slam_create(nullptr, &c, device, &s_);
@@ -355,6 +356,28 @@ class LaserSlam {
     return Unpack(rec_);
   }
   const msfl_slam_result& last_record() const { return rec_; }
+
+  // What the reference publishes per scan (PublishScan, laser_mapping.cc:418-440) and accumulates for its PLY dump (:214-217), for one of the
+  // last two scans fed (keep_clouds): the scan as a TimestampedPointCloud whose five clouds are the de-skewed ones, and cloud_full_res in the map frame.
+  struct ScanClouds { TimestampedPointCloud<PointTypeOriginal> scan; PointCloud<PointTypeOriginal> full_res_in_map; };
+  ScanClouds Clouds(int scan_index) {
+    const std::size_t n = static_cast<std::size_t>(max_scan_points_);
+    std::vector<msfl_point> a(n), b(n); std::vector<std::uint16_t> ring(n); std::vector<int> idx[4];
+    for (auto& v : idx) v.resize(n);
+    msfl_slam_clouds c{};
+    c.full_scan = a.data(); c.full_map = b.data(); c.ring = ring.data();
+    c.sharp_idx = idx[0].data(); c.less_sharp_idx = idx[1].data(); c.flat_idx = idx[2].data(); c.less_flat_idx = idx[3].data();
+    const msfl_status st = msfl_slam_get_clouds(s_, scan_index, &c, MSFL_MEM_HOST);
+    if (st != MSFL_OK) throw std::runtime_error(std::string("msfl_slam_get_clouds: ") + msfl_status_string(st) + " " + msfl_slam_last_error(s_));
+    ScanClouds o;
+    auto at = [&](const std::vector<msfl_point>& src, int i) { return PointXYZIRT{src[i].x, src[i].y, src[i].z, src[i].t, ring[i], src[i].t}; };
+    for (int i = 0; i < c.n_full; ++i) { o.scan.cloud_full_res->push_back(at(a, i)); o.full_res_in_map.push_back(at(b, i)); }
+    for (int k = 0; k < c.n_sharp; ++k) o.scan.cloud_corner_sharp->push_back(at(a, idx[0][k]));
+    for (int k = 0; k < c.n_less_sharp; ++k) o.scan.cloud_corner_less_sharp->push_back(at(a, idx[1][k]));
+    for (int k = 0; k < c.n_flat; ++k) o.scan.cloud_surf_flat->push_back(at(a, idx[2][k]));
+    for (int k = 0; k < c.n_less_flat; ++k) o.scan.cloud_surf_less_flat->push_back(at(a, idx[3][k]));
+    return o;
+  }
 
  private:
   void Enqueue(const PointCloud<PointTypeOriginal>& in, const ImuInputs* imu, msfl_slam_result* out) {
@@ -394,6 +417,7 @@ class LaserSlam {
   msfl_slam* s_ = nullptr;
   msfl_slam_result rec_{};
   int n_ = 0;
+  int max_scan_points_ = 0;
 };
 
 }  // namespace msfl

@@ -64,22 +64,10 @@ def other_scans(kind, n, seed=synth.SEED + 2):
 
 def world_drive(kind, n):
     """A drive through the world for the sequential replay (~0.4 m and a degree or two per scan): along the x = 0 street of the
-    outdoor world (relief followed, gentle weaving), down the corridor's axis."""
+    outdoor world (relief followed, gentle weaving), down the corridor's axis — examples/replay_synthetic.py:world_drive."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import replay_synthetic as rp
     w, _, _ = other_world(kind)
-    poses = []
-    for k in range(n):
-        a = k / max(n - 1, 1)
-        if kind == "outdoor":
-            y = -25.0 + 0.4 * k
-            x = 1.2 * np.sin(0.11 * k)
-            yaw = np.pi / 2 - np.arctan(1.2 * 0.11 * np.cos(0.11 * k) / 0.4) * 0.5
-            z = float(w.geom.ground(x, y)) + 1.8 + 0.02 * np.sin(0.5 * k)
-            poses.append(np.r_[x, y, z, synth.quat_from_euler(0.015 * np.sin(0.3 * k), 0.01 * np.cos(0.2 * k), yaw)])
-        elif kind == "corridor":
-            x = -20.0 + 0.4 * k
-            y = 0.3 * np.sin(0.15 * k)
-            poses.append(np.r_[x, y, 1.5 + 0.02 * np.sin(0.4 * k), synth.quat_from_euler(0.01 * np.sin(0.3 * k), 0.01 * np.cos(0.25 * k), 0.05 * np.sin(0.2 * k))])
-        else:
-            raise ValueError(kind)
-        del a
-    return np.array(poses)
+    return rp.world_drive(w, kind, n)

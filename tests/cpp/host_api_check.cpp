@@ -6,6 +6,7 @@
 //        | 7 f64 map pose of the reference-signature (8-argument) call, is_initialized = false
 //        | 7 f64 map pose of the 8-argument call, is_initialized = true (deskew branch)
 //        | 3 x (7 f64 odometry pose, 7 f64 map pose) of LaserSlam fed the same cloud three times
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -101,6 +102,22 @@ int main(int argc, char** argv) {
     // (with the truncated surf cloud the map gate may stay closed on these three scans: `mapped` is not asserted)
     slam_ok = slam_ok && !q0.mapped && q1.scan_index == 1 && q2.scan_index == 2 && rr.status_imu == 0 && rr.status_extract == 0 &&
               rr.n_surf_ds > 0 && rr.n_surf_ds <= rr.n_less_sharp;
+  }
+  {
+    // keep_clouds through the mirror: the scan's clouds after (here: no) IMU passes and cloud_full_res in the map frame
+    msfl::LaserSlam slam3(0, n, 16, msfl::Rigid3d(std::array<double, 7>{{guess[0], guess[1], guess[2], guess[3], guess[4], guess[5], guess[6]}}), false, true);
+    const auto p0 = slam3.AddLaserScan(cloud);
+    const auto cl = slam3.Clouds(0);
+    bool same = cl.scan.cloud_full_res->size() == scan.cloud_full_res->size() && cl.scan.cloud_corner_sharp->size() == scan.cloud_corner_sharp->size() &&
+                cl.scan.cloud_surf_less_flat->size() == scan.cloud_surf_less_flat->size() && cl.full_res_in_map.size() == scan.cloud_full_res->size();
+    for (std::size_t i = 0; same && i < scan.cloud_full_res->size(); i += 97) {
+      const auto& a = (*cl.scan.cloud_full_res)[i]; const auto& b = (*scan.cloud_full_res)[i];
+      same = a.x == b.x && a.y == b.y && a.z == b.z && a.ring == b.ring;
+      const msfl::Vector3d w = p0.map * msfl::Vector3d{{(double)b.x, (double)b.y, (double)b.z}};
+      const auto& m = cl.full_res_in_map[i];
+      same = same && std::fabs(m.x - (float)w[0]) < 1e-4f && std::fabs(m.y - (float)w[1]) < 1e-4f && std::fabs(m.z - (float)w[2]) < 1e-4f;
+    }
+    slam_ok = slam_ok && same;
   }
   FILE* o = fopen(argv[2], "wb");
   auto v = pose.ToVector7(); auto w = rel.ToVector7();

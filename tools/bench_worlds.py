@@ -53,7 +53,27 @@ def _register_stats(h, pipe, d_guess, sync, reps):
     return t_reg, k_ms, cand, n_feat
 
 
-def measure_worlds(device=0, checker=None, scans=256, reps=5, spot=3, kinds=("outdoor", "corridor"), copies=4):
+def _slam_replay(kind, n):
+    """BASELINE configs[2]'s per-scan step on a drive through that world, in torch-free child processes like tools/bench_stages.py
+    (examples/replay_synthetic.py --world): ms per scan synchronous / pipelined, ATE, gate-closed scans."""
+    import subprocess
+    out = {}
+    for mode in ("slam", "slam-pipelined"):
+        cp = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "replay_synthetic.py"), "--scans", str(n), "--mode", mode, "--world", kind],
+                            capture_output=True, text=True, timeout=600)
+        if cp.returncode != 0:
+            raise RuntimeError("SLAM replay child failed: " + cp.stderr[-2000:])
+        out[mode] = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = out["slam"], out["slam-pipelined"]
+    return {"scans": n, "ms_per_scan_synchronous": a["ms_per_scan_end_to_end"], "ms_per_scan_pipelined": b["ms_per_scan_end_to_end"],
+            "ate_rmse_m": a["ate_rmse_m"], "same_final_error": a["final_error_m_rad"] == b["final_error_m_rad"],
+            "map_points": a["map_points"], "mean_surrounded_map_points": a["mean_surrounded_map_points"],
+            "mean_features_after_voxel": a["mean_features_after_voxel"], "mapping_gate_closed_scans": a["mapping_gate_closed_scans"],
+            "note": "parity of this replay against the oracle-driven loop: tests/test_gpu_replay.py::test_device_resident_slam_step_in_the_other_worlds; "
+                    "the corridor's ATE is LOAM's own failure along the unobservable axis (the CPU loop's too)"}
+
+
+def measure_worlds(device=0, checker=None, scans=256, reps=5, spot=3, kinds=("outdoor", "corridor"), copies=4, slam_scans=60):
     """`scans` distinct sweeps per world, each registered from `copies` different guesses: scans x copies registrations per step (1 024
     by default, the batch of bench.py's headline, so that registrations/s compare like for like; registrations are independent units)."""
     import torch
@@ -113,6 +133,8 @@ def measure_worlds(device=0, checker=None, scans=256, reps=5, spot=3, kinds=("ou
         del pipe
         h.close()
         scans = n_sweeps
+        if slam_scans > 0:
+            out[kind]["slam_step"] = _slam_replay(kind, slam_scans)
     return out
 
 
