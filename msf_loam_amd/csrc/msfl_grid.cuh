@@ -369,6 +369,9 @@ grid_rebuild_kernel(const float4* __restrict__ pool_in, float4* __restrict__ poo
   __shared__ unsigned long long s_ent[LDS_CAP];
   __shared__ int s_wsum[THREADS / 64];
   __shared__ int s_carry, s_unsorted;
+  constexpr int kLongRun = 16, kLongCap = LDS_CAP / 16 > 1024 ? 1024 : LDS_CAP / 16;      // runs the head thread hands to a wavefront
+  __shared__ int s_long[kLongCap][3];
+  __shared__ int s_nlong;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = st->n_touched;
   if (LARGE && st->n_big == 0) return;
@@ -408,8 +411,17 @@ grid_rebuild_kernel(const float4* __restrict__ pool_in, float4* __restrict__ poo
     }
     __syncthreads();
     grid_bitonic<THREADS>(ent, P, s_unsorted ? 2 : P);
-    // voxel runs: heads, their ranks (block scan over chunks of THREADS entries), one thread per head walks its run
+    // voxel runs: heads, their ranks (block scan over chunks of THREADS entries), one thread per head walks its run.
+    // Round 5: a run of more than kLongRun entries is not walked by its head's thread (one dependent index -> point gather per entry: a
+    // 0.4 m voxel on a corridor wall 1.5 m from the sensor receives hundreds of points per scan and its thread's chain was the whole
+    // kernel: 279 us per insert) but queued and summed by a whole wavefront afterwards: 64 entries per coalesced gather, then the same
+    // sequential f32 additions in the same order through scalar broadcasts (bit-identical); short runs request four points at a time.
     float4* out = pool_out + woff;
+    auto entry_point = [&](int j) __attribute__((always_inline)) {
+      const int ord = (int)(unsigned)ent[j];
+      return ord < n_old ? pool_in[o_start + ord] : xf[svals[ns + ord - n_old]];
+    };
+    if (tid == 0) s_nlong = 0;
     for (int base = 0; base < E; base += THREADS) {
       const int i = base + tid;
       unsigned v = 0; bool head = false;
@@ -424,20 +436,49 @@ grid_rebuild_kernel(const float4* __restrict__ pool_in, float4* __restrict__ poo
       int r = s_carry + before;
       for (int w = 0; w < wave; w++) r += s_wsum[w];
       if (head) {
-        float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
-        int j = i;
-        for (; j < E && (unsigned)(ent[j] >> 32) == v; j++) {
-          const int ord = (int)(unsigned)ent[j];
-          const float4 p = ord < n_old ? pool_in[o_start + ord] : xf[svals[ns + ord - n_old]];
-          sx += p.x; sy += p.y; sz += p.z; sw += p.w;
+        int j = i + 1;
+        while (j < E && (unsigned)(ent[j] >> 32) == v) j++;                 // end of the run (LDS / scratch reads only)
+        const int L = j - i;
+        int slot = -1;
+        if (L > kLongRun) { slot = atomicAdd(&s_nlong, 1); if (slot >= kLongCap) slot = -1; }
+        if (slot >= 0) { s_long[slot][0] = r; s_long[slot][1] = i; s_long[slot][2] = L; }
+        else {
+          float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+          for (int q = i; q < j; q += 4) {                                 // four gathers in flight, added in run order
+            const float4 p0 = entry_point(q), p1 = entry_point(min(q + 1, j - 1)), p2 = entry_point(min(q + 2, j - 1)), p3 = entry_point(min(q + 3, j - 1));
+            sx += p0.x; sy += p0.y; sz += p0.z; sw += p0.w;
+            if (q + 1 < j) { sx += p1.x; sy += p1.y; sz += p1.z; sw += p1.w; }
+            if (q + 2 < j) { sx += p2.x; sy += p2.y; sz += p2.z; sw += p2.w; }
+            if (q + 3 < j) { sx += p3.x; sy += p3.y; sz += p3.z; sw += p3.w; }
+          }
+          const float c = (float)L;
+          out[r] = make_float4(sx / c, sy / c, sz / c, sw / c);
         }
-        const float c = (float)(j - i);
-        out[r] = make_float4(sx / c, sy / c, sz / c, sw / c);
       }
       __syncthreads();
       if (tid == THREADS - 1) s_carry = r + (head ? 1 : 0);
       __syncthreads();
     }
+    __syncthreads();
+    {
+      const int n_long = min(s_nlong, kLongCap);
+      for (int q = wave; q < n_long; q += THREADS / 64) {
+        const int r = s_long[q][0], i0 = s_long[q][1], L = s_long[q][2];
+        float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+        float4 p = entry_point(i0 + min(lane, L - 1));
+        for (int c0 = 0; c0 < L; c0 += 64) {
+          const float4 pc = p;
+          const int m = min(64, L - c0);
+          if (c0 + 64 < L) p = entry_point(i0 + c0 + 64 + min(lane, L - c0 - 64 - 1));      // the next 64 entries load while these are summed
+          for (int e = 0; e < m; e++) {
+            sx += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.x), e)); sy += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.y), e));
+            sz += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.z), e)); sw += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.w), e));
+          }
+        }
+        if (lane == 0) { const float c = (float)L; out[r] = make_float4(sx / c, sy / c, sz / c, sw / c); }
+      }
+    }
+    __syncthreads();
     if (tid == 0) { const int R = s_carry; t_cnt[t] = R; atomicAdd(&st->delta_points, R - n_old); }
     __syncthreads();
   }
