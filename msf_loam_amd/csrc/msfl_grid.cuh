@@ -436,8 +436,12 @@ grid_rebuild_kernel(const float4* __restrict__ pool_in, float4* __restrict__ poo
       int r = s_carry + before;
       for (int w = 0; w < wave; w++) r += s_wsum[w];
       if (head) {
-        int j = i + 1;
-        while (j < E && (unsigned)(ent[j] >> 32) == v) j++;                 // end of the run (LDS / scratch reads only)
+        // end of the run: the entries are sorted, so gallop (1, 2, 4, ... entries ahead) and bisect — a run of 500 entries costs ~18
+        // dependent LDS reads instead of 500 (the workgroup's barrier waits for the longest of its heads)
+        int lo = i, step = 1;
+        while (lo + step < E && (unsigned)(ent[lo + step] >> 32) == v) { lo += step; step <<= 1; }
+        int j = min(lo + step, E);
+        while (j - lo > 1) { const int mid = (lo + j) >> 1; if ((unsigned)(ent[mid] >> 32) == v) lo = mid; else j = mid; }
         const int L = j - i;
         int slot = -1;
         if (L > kLongRun) { slot = atomicAdd(&s_nlong, 1); if (slot >= kLongCap) slot = -1; }
