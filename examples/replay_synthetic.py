@@ -269,6 +269,7 @@ def main():
     ap.add_argument("--imu", action="store_true", help="feed a synthetic pre-integration with every scan (UndistortScan, then the is_initialized branch from scan 50)")
     ap.add_argument("--world", choices=["room", "outdoor", "corridor"], default="room",
                     help="room: the SURVEY 8d world and its loop; outdoor / corridor: msf_loam_amd/worlds.py with a drive down the street / the axis (round 5)")
+    ap.add_argument("--beams", type=int, choices=[16, 64], default=16, help="64: the KITTI-scale sensor of BASELINE configs[3] (64 x 1 900, -24.8 .. +2 degrees)")
     ap.add_argument("--keep-clouds", action="store_true", help="msfl_slam_config.keep_clouds = 1 and fetch every scan's clouds (what PublishScan would publish)")
     args = ap.parse_args()
     if args.world == "room":
@@ -283,7 +284,8 @@ def main():
                           "final_error_m_rad": synth.pose_error(est[-1], truth[-1]),
                           "latency_ms_per_scan": ms, "note": "single-scan host-pointer calls (includes PCIe staging)"}))
         return
-    scans = [synth.make_scan(world, truth[k], synth.SEED + 5000 + k) for k in range(args.scans)]
+    kw = dict(n_beams=64, n_az=1900, elev=(-24.8, 2.0)) if args.beams == 64 else {}
+    scans = [synth.make_scan(world, truth[k], synth.SEED + 5000 + k, **kw) for k in range(args.scans)]
     import gc
     gc.collect(); gc.disable()
     est, recs, ms = run_slam(world, truth, pipelined=args.mode == "slam-pipelined", scans=scans, quirks=args.reference_quirks,
@@ -291,7 +293,7 @@ def main():
     last = recs[-1]
     if args.dump_poses:
         np.save(args.dump_poses, est)
-    print(json.dumps({"mode": args.mode, "world": args.world, "keep_clouds": bool(args.keep_clouds), "scans": args.scans, "reference_quirks": bool(args.reference_quirks), "imu": bool(args.imu),
+    print(json.dumps({"mode": args.mode, "world": args.world, "beams": args.beams, "keep_clouds": bool(args.keep_clouds), "scans": args.scans, "reference_quirks": bool(args.reference_quirks), "imu": bool(args.imu),
                       "ate_rmse_m": ate(est, truth),
                       "final_error_m_rad": synth.pose_error(est[-1], truth[-1]), "ms_per_scan_end_to_end": ms,
                       "scans_per_s": 1e3 / ms if ms else None,

@@ -140,6 +140,8 @@ struct msfl_handle_s {
   int vox_nonfinite_cloud = -1;
   const float4* vox_staged_pts = nullptr;
   bool voxel_no_big = false;              // MSFL_VOXEL_NO_BIG=1: lists beyond the LDS forms go straight to the device-wide form (A/B of the round-5 big form)
+  int odom_bin_split = -1;         // the scan-to-scan index build: -1 = several workgroups per cloud when the call holds few pairs with long clouds, 0 / 1 = never / always (MSFL_ODOM_BIN_SPLIT)
+  int prep_split = -1;             // workgroups per scan of the extraction's ring split: -1 = by batch size, 1 = the one-workgroup kernel (MSFL_PREP_SPLIT)
   bool voxel_force_global = false;        // MSFL_VOXEL_GLOBAL=1: the batched voxel filter keeps the device-wide radix-sort form (A/B testing)
   long long odom_wave_max_targets = -1;   // MSFL_ODOM_WAVE_MAX_TARGETS: previous-scan points up to which a small batch takes the one-wavefront-per-query kernel (default 4096 per pair)
   bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)
@@ -576,6 +578,8 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
   if (const char* e = std::getenv("MSFL_ODOM_WAVE_MAX_TARGETS")) h->odom_wave_max_targets = std::atoll(e);
   if (const char* e = std::getenv("MSFL_VOXEL_GLOBAL")) h->voxel_force_global = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSFL_VOXEL_NO_BIG")) h->voxel_no_big = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MSFL_ODOM_BIN_SPLIT")) h->odom_bin_split = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("MSFL_PREP_SPLIT")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) h->prep_split = g; }
   *out = h;
   return MSFL_OK;
 }

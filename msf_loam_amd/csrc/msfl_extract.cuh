@@ -318,6 +318,328 @@ __global__ void __launch_bounds__(1024) extract_prepare_kernel(ExtractView v, Ex
   if (tid == 0) v.n_full[b] = N;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same ring split for a call with FEW scans (the SLAM step hands over one): G workgroups per scan, 16 G slices.
+// One 64-beam sweep (~130 k points, two f64 atan2 each) kept the single workgroup above busy for 326 us while 255 compute
+// units idled (profiles/r05_slam64_*).  The two slice passes need the populations of ALL slices between them, so the
+// split is three launches on the stream instead of a device-wide barrier inside one:
+//   extract_prepare_count_kernel    pass A of 16 slices per workgroup -> populations of (slice, ring), per-workgroup ring totals
+//   extract_prepare_scatter_kernel  cursors from those, the early-wrap pre-pass (every workgroup repeats it: 256 points), pass B
+//   extract_prepare_finish_kernel   wrap test across slices, late-wrap time fix-up and ring ids of the rings r = g (mod G)
+// A slice is still a contiguous piece of the driver-order cloud walked by one wavefront with the arithmetic of the kernel
+// above, and a wrap point is the ring's smallest output index with a < a_prev whoever finds it: outputs are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct PrepSplitView {
+  int* cnt;            // B x S x kMaxRings: population of (slice, ring)
+  int* start;          // B x S x kMaxRings: first output index of (slice, ring)
+  double* firsta;      // B x S x kMaxRings: raw angle of the first / last point of (slice, ring); defined where cnt > 0
+  double* lasta;
+  int* wg_tot;         // B x G x kMaxRings: ring populations of a workgroup's 16 slices
+  int* head;           // B x G x 4: first valid point, bad ring seen, highest ring id
+  int* wrap;           // B x G x kMaxRings: smallest wrap index found inside the workgroup's slices (INT_MAX: none)
+  int* early;          // B x kMaxRings: the early wrap points (INT_MAX: none)
+  double* start_ori;   // B
+  int G;
+};
+inline size_t prep_split_bytes(int B, int G) {
+  const size_t S = 16 * (size_t)G;
+  return (size_t)B * (S * kMaxRings * (2 * sizeof(int) + 2 * sizeof(double)) + (size_t)G * kMaxRings * 2 * sizeof(int) + (size_t)G * 4 * sizeof(int) +
+                      kMaxRings * sizeof(int) + sizeof(double)) + 256;
+}
+inline PrepSplitView prep_split_view(void* base, int B, int G) {
+  const size_t S = 16 * (size_t)G;
+  PrepSplitView sv;
+  char* p = static_cast<char*>(base);
+  sv.firsta = reinterpret_cast<double*>(p); p += (size_t)B * S * kMaxRings * sizeof(double);
+  sv.lasta = reinterpret_cast<double*>(p); p += (size_t)B * S * kMaxRings * sizeof(double);
+  sv.start_ori = reinterpret_cast<double*>(p); p += (size_t)B * sizeof(double);
+  sv.cnt = reinterpret_cast<int*>(p); p += (size_t)B * S * kMaxRings * sizeof(int);
+  sv.start = reinterpret_cast<int*>(p); p += (size_t)B * S * kMaxRings * sizeof(int);
+  sv.wg_tot = reinterpret_cast<int*>(p); p += (size_t)B * G * kMaxRings * sizeof(int);
+  sv.wrap = reinterpret_cast<int*>(p); p += (size_t)B * G * kMaxRings * sizeof(int);
+  sv.head = reinterpret_cast<int*>(p); p += (size_t)B * G * 4 * sizeof(int);
+  sv.early = reinterpret_cast<int*>(p);
+  sv.G = G;
+  return sv;
+}
+
+constexpr int kPrepGroups = 4;           // 64-point groups per iteration with their loads issued up front (as above)
+
+// slice [w0, w1) of wavefront `wave` of workgroup g: slices are multiples of 64 points, so a 64-point group never straddles two
+__device__ __forceinline__ void prep_slice_bounds(int n, int S, int sl, int& w0, int& w1) {
+  const int slice = ((n + S - 1) / S + 63) & ~63;
+  w0 = (int)min((long long)sl * slice, (long long)n); w1 = min(w0 + slice, n);
+}
+
+// the verdict of pass A over the whole scan, from the workgroups' reports: [0] first valid point, [1] bad ring, [2] ring-id bits
+__device__ __forceinline__ void prep_head_reduce(const int* __restrict__ head, int G, int* s_flag) {
+  int f = 0x7fffffff, bd = 0, rm = 0;
+  for (int g = 0; g < G; g++) { f = min(f, head[4 * g]); bd |= head[4 * g + 1]; rm = max(rm, head[4 * g + 2]); }
+  s_flag[0] = f; s_flag[1] = bd; s_flag[2] = 32 - __clz(rm | 1);
+}
+
+__device__ __forceinline__ double prep_rel_angle(const float4 p, double start_ori) {
+  // :139-142, see rel_angle in extract_prepare_kernel
+  const double two_pi = 2 * 3.14159265358979323846;
+  const double ori = -atan2((double)p.y, (double)p.x);
+  double a = ori - start_ori + two_pi;
+  if (a >= two_pi) a -= two_pi;
+  if (a >= two_pi) a -= two_pi;
+  return a;
+}
+
+__global__ void __launch_bounds__(1024) extract_prepare_count_kernel(ExtractView v, ExtractParams prm, PrepSplitView sv) {
+  __shared__ int s_cur[16][kMaxRings];
+  __shared__ int s_first[16], s_badw[16], s_rmax[16];
+  const int g = blockIdx.x, b = blockIdx.y, G = sv.G, S = 16 * G, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int o = v.off[b];
+  const int n = v.off[b + 1] - o;
+  const float4* in = v.in_pts + o;
+  const uint16_t* in_ring = v.in_ring + o;
+  for (int k = tid; k < 16 * kMaxRings; k += 1024) (&s_cur[0][0])[k] = 0;
+  __syncthreads();
+  int w0, w1;
+  prep_slice_bounds(n, S, 16 * g + wave, w0, w1);
+  int first = 0x7fffffff, bad = 0, rmax = 0;
+  for (int g0 = w0; g0 < w1; g0 += 64 * kPrepGroups) {
+    float4 pp[kPrepGroups]; int rr[kPrepGroups];
+#pragma unroll
+    for (int u = 0; u < kPrepGroups; u++) {
+      const int i = g0 + 64 * u + lane;
+      pp[u] = make_float4(0, 0, 0, 0); rr[u] = 0;
+      if (i < w1) { pp[u] = in[i]; rr[u] = in_ring[i]; }
+    }
+#pragma unroll
+    for (int u = 0; u < kPrepGroups; u++) {
+      const int gq = g0 + 64 * u;
+      if (gq >= w1) break;
+      const int i = gq + lane;
+      bool valid = false;
+      int r = -1;
+      if (i < w1) {
+        valid = point_valid(pp[u], prm.min_range_sq);
+        if (valid) { r = rr[u]; if (r >= kMaxRings) { bad = 1; valid = false; } }   // CHECK_LT(point.ring, 128), :136
+      }
+      const unsigned long long any_valid = __ballot(valid);
+      if (any_valid && first == 0x7fffffff) first = gq + (__ffsll((long long)any_valid) - 1);
+      if (valid) { atomicAdd(&s_cur[wave][r], 1); rmax = max(rmax, r); }
+    }
+  }
+  bad = __any(bad) ? 1 : 0;
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) rmax = max(rmax, __shfl_xor(rmax, o2));
+  if (lane == 0) { s_first[wave] = first; s_badw[wave] = bad; s_rmax[wave] = rmax; }
+  __syncthreads();
+  int* cnt = sv.cnt + ((size_t)b * S + 16 * g) * kMaxRings;
+  for (int k = tid; k < 16 * kMaxRings; k += 1024) cnt[k] = (&s_cur[0][0])[k];
+  if (tid < kMaxRings) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) t += s_cur[w][tid];
+    sv.wg_tot[((size_t)b * G + g) * kMaxRings + tid] = t;
+  }
+  if (tid == 0) {
+    int f = 0x7fffffff, bd = 0, rm = 0;
+    for (int w = 0; w < 16; w++) { f = min(f, s_first[w]); bd |= s_badw[w]; rm = max(rm, s_rmax[w]); }
+    int* head = sv.head + ((size_t)b * G + g) * 4;
+    head[0] = f; head[1] = bd; head[2] = rm; head[3] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(1024) extract_prepare_scatter_kernel(ExtractView v, ExtractParams prm, PrepSplitView sv) {
+  __shared__ int s_off[kMaxRings + 1];
+  __shared__ int s_wrap[kMaxRings];
+  __shared__ int s_cur[16][kMaxRings];
+  __shared__ int s_flag[3];
+  __shared__ double s_start_ori;
+  __shared__ double s_lasta[16][kMaxRings];
+  __shared__ double s_firsta[16][kMaxRings];
+  __shared__ double s_pre_last[kMaxRings];
+  __shared__ int s_pre_cnt[kMaxRings];
+  __shared__ int s_early[kMaxRings];
+  const int g = blockIdx.x, b = blockIdx.y, G = sv.G, S = 16 * G, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int o = v.off[b];
+  const int n = v.off[b + 1] - o;
+  const float4* in = v.in_pts + o;
+  const uint16_t* in_ring = v.in_ring + o;
+  if (tid == 0) prep_head_reduce(sv.head + (size_t)b * G * 4, G, s_flag);
+  for (int k = tid; k < 16 * kMaxRings; k += 1024) (&s_lasta[0][0])[k] = __longlong_as_double(0x7ff8000000000000ll);
+  // ring totals of the scan and what the workgroups in front of this one hold of each ring: at most 16 + 16 independent loads
+  if (tid < kMaxRings) {
+    int before = 0, total = 0;
+    for (int q = 0; q < G; q++) { const int t = sv.wg_tot[((size_t)b * G + q) * kMaxRings + tid]; if (q < g) before += t; total += t; }
+    const int* cnt = sv.cnt + ((size_t)b * S + 16 * g) * kMaxRings + tid;
+    int c[16];
+#pragma unroll
+    for (int w = 0; w < 16; w++) c[w] = cnt[w * kMaxRings];
+#pragma unroll
+    for (int w = 0; w < 16; w++) { s_cur[w][tid] = before; before += c[w]; }
+    s_wrap[tid] = total;                                      // borrowed as the ring total
+  }
+  __syncthreads();
+  if (s_flag[1] || s_flag[0] == 0x7fffffff) {
+    if (g == 0) {
+      if (tid == 0) {
+        v.status[b] = s_flag[1] ? 5 /*MSFL_BAD_RING*/ : 3 /*MSFL_BAD_ARG: empty valid cloud, CHECK :186,:200*/;
+        v.n_full[b] = 0; v.n_sharp[b] = 0; v.n_less_sharp[b] = 0; v.n_flat[b] = 0; v.n_less_flat[b] = 0;
+      }
+      if (tid <= kMaxRings) v.ring_tab[b * (kMaxRings + 1) + tid] = 0;
+    }
+    return;
+  }
+  if (tid == 0) {
+    int run = 0;
+    for (int r = 0; r < kMaxRings; r++) { s_off[r] = run; run += s_wrap[r]; }
+    s_off[kMaxRings] = run;
+    const float4 f = in[s_flag[0]];
+    s_start_ori = -atan2((double)f.y, (double)f.x);       // :131
+  }
+  __syncthreads();
+  if (g == 0 && tid <= kMaxRings) v.ring_tab[b * (kMaxRings + 1) + tid] = s_off[tid];
+  if (tid < kMaxRings) {
+    int* start = sv.start + ((size_t)b * S + 16 * g) * kMaxRings + tid;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const int c = s_cur[w][tid] + s_off[tid]; s_cur[w][tid] = c; start[w * kMaxRings] = c; }
+    s_wrap[tid] = 0x7fffffff;
+    s_pre_last[tid] = __longlong_as_double(0x7ff8000000000000ll); s_pre_cnt[tid] = 0; s_early[tid] = 0x7fffffff;
+  }
+  __syncthreads();
+  const int ring_bits = __builtin_amdgcn_readfirstlane(s_flag[2]);
+  const double start_ori = s_start_ori;
+  const double two_pi = 2 * 3.14159265358979323846;
+  float4* out_pts = v.full_pts + o;
+  // ---- early wraps over the first 256 points of the CLOUD (see the kernel above; any prefix gives the same outputs) ----
+  if (wave == 0) {
+    const int pre_end = min(n, 256);
+    for (int gq = 0; gq < pre_end; gq += 64) {
+      const int i = gq + lane;
+      float4 p = make_float4(0, 0, 0, 0);
+      int r = -1;
+      bool valid = false;
+      if (i < pre_end) { p = in[i]; valid = point_valid(p, prm.min_range_sq); if (valid) r = in_ring[i]; }
+      const unsigned long long m = same_ring_lanes(valid, r, ring_bits);
+      const unsigned long long below = m & ((1ull << lane) - 1ull);
+      const double a = valid ? prep_rel_angle(p, start_ori) : 0.0;
+      const int pl = below ? 63 - __clzll((long long)below) : lane;
+      double a_prev = __shfl(a, pl);
+      if (valid) {
+        const int seen = s_pre_cnt[r];
+        bool has_prev = below != 0;
+        if (!has_prev) { a_prev = s_pre_last[r]; has_prev = !isnan(a_prev); }
+        if ((m >> lane) == 1ull) { s_pre_last[r] = a; s_pre_cnt[r] = seen + __popcll(m); }
+        if (has_prev && a < a_prev) atomicMin(&s_early[r], s_off[r] + seen + __popcll(below));
+      }
+    }
+  }
+  __syncthreads();
+  // ---- pass B over this wavefront's slice ----
+  int w0, w1;
+  prep_slice_bounds(n, S, 16 * g + wave, w0, w1);
+  for (int g0 = w0; g0 < w1; g0 += 64 * kPrepGroups) {
+    float4 pp[kPrepGroups]; int rr[kPrepGroups];
+#pragma unroll
+    for (int u = 0; u < kPrepGroups; u++) {
+      const int i = g0 + 64 * u + lane;
+      pp[u] = make_float4(0, 0, 0, 0); rr[u] = 0;
+      if (i < w1) { pp[u] = in[i]; rr[u] = in_ring[i]; }
+    }
+#pragma unroll
+    for (int u = 0; u < kPrepGroups; u++) {
+      const int gq = g0 + 64 * u;
+      if (gq >= w1) break;
+      const int i = gq + lane;
+      const float4 p = pp[u];
+      int r = -1;
+      bool valid = false;
+      if (i < w1) {
+        valid = point_valid(p, prm.min_range_sq);
+        if (valid) r = rr[u];
+      }
+      int dst = 0;
+      const unsigned long long m = same_ring_lanes(valid, r, ring_bits);
+      const unsigned long long below = m & ((1ull << lane) - 1ull);
+      double a = 0.0;
+      if (valid) {
+        const int cur = s_cur[wave][r];
+        dst = cur + __popcll(below);
+        if (below == 0) s_cur[wave][r] = cur + __popcll(m);
+        a = prep_rel_angle(p, start_ori);
+      }
+      const int pl = below ? 63 - __clzll((long long)below) : lane;
+      double a_prev = __shfl(a, pl);
+      if (valid) {
+        bool has_prev = below != 0;
+        if (!has_prev) {
+          a_prev = s_lasta[wave][r];
+          has_prev = !isnan(a_prev);
+          if (!has_prev) s_firsta[wave][r] = a;
+        }
+        if ((m >> lane) == 1ull) s_lasta[wave][r] = a;
+        if (has_prev && a < a_prev) atomicMin(&s_wrap[r], dst);
+        const double aw = dst >= s_early[r] ? a + two_pi : a;
+        out_pts[dst] = make_float4(p.x, p.y, p.z, (float)(aw / two_pi * prm.scan_period));
+      }
+    }
+  }
+  __syncthreads();
+  double* firsta = sv.firsta + ((size_t)b * S + 16 * g) * kMaxRings;
+  double* lasta = sv.lasta + ((size_t)b * S + 16 * g) * kMaxRings;
+  for (int k = tid; k < 16 * kMaxRings; k += 1024) { firsta[k] = (&s_firsta[0][0])[k]; lasta[k] = (&s_lasta[0][0])[k]; }
+  if (tid < kMaxRings) {
+    sv.wrap[((size_t)b * G + g) * kMaxRings + tid] = s_wrap[tid];
+    if (g == 0) sv.early[(size_t)b * kMaxRings + tid] = s_early[tid];
+  }
+  if (g == 0 && tid == 0) sv.start_ori[b] = start_ori;
+}
+
+__global__ void __launch_bounds__(1024) extract_prepare_finish_kernel(ExtractView v, ExtractParams prm, PrepSplitView sv) {
+  __shared__ int s_cnt[16 * kMaxRings];          // populations of the owned rings: [j][s], j-th owned ring, S slices (S x 128 / G = 2 048 entries)
+  __shared__ int s_wrap[kMaxRings];              // per owned ring j
+  __shared__ int s_flag[3];
+  const int g = blockIdx.x, b = blockIdx.y, G = sv.G, S = 16 * G, own = kMaxRings / G, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int o = v.off[b];
+  if (tid == 0) prep_head_reduce(sv.head + (size_t)b * G * 4, G, s_flag);
+  __syncthreads();
+  if (s_flag[1] || s_flag[0] == 0x7fffffff) return;          // the scatter kernel reported it
+  const int* cnt = sv.cnt + (size_t)b * S * kMaxRings;
+  for (int k = tid; k < own * S; k += 1024) { const int j = k / S, sl = k - j * S; s_cnt[k] = cnt[sl * kMaxRings + g + G * j]; }
+  if (tid < own) {
+    int w = 0x7fffffff;
+    for (int q = 0; q < G; q++) w = min(w, sv.wrap[((size_t)b * G + q) * kMaxRings + g + G * tid]);
+    s_wrap[tid] = w;
+  }
+  __syncthreads();
+  // predecessor in an earlier slice: the first point of (slice, ring) against the last point of the nearest earlier slice that holds the ring
+  const double* firsta = sv.firsta + (size_t)b * S * kMaxRings;
+  const double* lasta = sv.lasta + (size_t)b * S * kMaxRings;
+  const int* start = sv.start + (size_t)b * S * kMaxRings;
+  for (int k = tid; k < own * S; k += 1024) {
+    const int j = k / S, sl = k - j * S, r = g + G * j;
+    if (s_cnt[k] == 0) continue;
+    int p = sl - 1;
+    while (p >= 0 && s_cnt[j * S + p] == 0) p--;
+    if (p >= 0 && firsta[sl * kMaxRings + r] < lasta[p * kMaxRings + r]) atomicMin(&s_wrap[j], start[sl * kMaxRings + r]);
+  }
+  __syncthreads();
+  const int* tab = v.ring_tab + b * (kMaxRings + 1);
+  const double start_ori = sv.start_ori[b];
+  const double two_pi = 2 * 3.14159265358979323846;
+  float4* out_pts = v.full_pts + o;
+  uint16_t* out_ring = v.full_ring + o;
+  for (int j = wave; j < own; j += 16) {
+    const int r = g + G * j, r0 = tab[r], r1 = tab[r + 1];
+    const int lo = s_wrap[j], hi = min(sv.early[(size_t)b * kMaxRings + r], r1);
+    if (lo < hi) {                                           // a late wrap: the +2 pi time for what lies behind it (lo = INT_MAX: none)
+      for (int i = lo + lane; i < hi; i += 64) {
+        const float4 p = out_pts[i];
+        out_pts[i].w = (float)((prep_rel_angle(p, start_ori) + two_pi) / two_pi * prm.scan_period);
+      }
+    }
+    for (int i = r0 + lane; i < r1; i += 64) out_ring[i] = (uint16_t)r;
+  }
+  if (g == 0 && tid == 0) v.n_full[b] = tab[kMaxRings];
+}
+
 __device__ __forceinline__ int find_scan_off(const int* __restrict__ off, int n_scans, int g) {
   int lo = 0, hi = n_scans;
   while (hi - lo > 1) {
@@ -644,7 +966,9 @@ __global__ void __launch_bounds__(kCompactThreads) extract_compact_kernel(Extrac
   static_assert(kMaxRings == 128, "two rings per lane in the prefix below");
   __shared__ int s_pref[4][kMaxRings + 1];
   __shared__ int s_tab[kMaxRings + 1];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // grid (G, B): the G workgroups of a scan take interleaved 4 096-entry pieces of its lists (G > 1 when the call holds few scans:
+  // one workgroup walked a 64-beam sweep's 100 k less-flat entries in 80 us); each repeats the 4 x 128 prefix, which is nothing
+  const int g = blockIdx.x, G = gridDim.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int o = v.off[b];
   const int* cnt = v.ring_cnt + (size_t)b * kMaxRings * 4;
   const int* tab = v.ring_tab + b * (kMaxRings + 1);
@@ -660,7 +984,7 @@ __global__ void __launch_bounds__(kCompactThreads) extract_compact_kernel(Extrac
     if (lane == 63) s_pref[wave][kMaxRings] = incl;
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && g == 0) {
     v.n_sharp[b] = s_pref[0][kMaxRings]; v.n_less_sharp[b] = s_pref[1][kMaxRings];
     v.n_flat[b] = s_pref[2][kMaxRings]; v.n_less_flat[b] = s_pref[3][kMaxRings];
     if (!ok) v.n_full[b] = (v.status[b] == 7) ? v.n_full[b] : 0;
@@ -675,7 +999,7 @@ __global__ void __launch_bounds__(kCompactThreads) extract_compact_kernel(Extrac
     const int total = s_pref[L][kMaxRings];
     // four entries per thread and round: the searches, then the four loads together, then the stores (one entry per
     // round left every round waiting on its own load)
-    for (int k0 = tid; k0 < total; k0 += 4 * kCompactThreads) {
+    for (int k0 = g * 4 * kCompactThreads + tid; k0 < total; k0 += G * 4 * kCompactThreads) {
       int src[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -696,7 +1020,7 @@ __global__ void __launch_bounds__(kCompactThreads) extract_compact_kernel(Extrac
     const pose7 T = load_pose(extrinsic);
     const int N = v.n_full[b];
     float4* c = v.full_pts + o;
-    for (int i = tid; i < N; i += kCompactThreads) {
+    for (int i = g * kCompactThreads + tid; i < N; i += G * kCompactThreads) {
       const float4 p = c[i];
       const float3 t = transform_point_f32(T, p.x, p.y, p.z);
       c[i] = make_float4(t.x, t.y, t.z, p.w);

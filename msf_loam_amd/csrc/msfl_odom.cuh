@@ -327,9 +327,11 @@ assoc_scan2scan_wave_kernel(BatchView bv, OdomView ov, const double* __restrict_
 // are non-decreasing in array order (what scan registration produces, msf_loam_node.cc:243-356)
 // they select exactly {j > closest, ring <= id + 2.5} and {j < closest, ring >= id - 2.5}, and the
 // running strict '<' minima become lexicographic minima over (distance, index).  Pairs whose
-// cloud is not ring-monotone, has a ring >= 256, more than 65 535 points, a non-finite or
-// > 512 m coordinate, or a footprint of more than 40 960 columns keep the brute-force kernel
-// above (mode[b] = 1); results are identical either way.
+// cloud is not ring-monotone, has a ring >= 256, 2^24 points or more (the sorted copy's index field), more than 65 535
+// points in ONE column (the u16 counters; found after the histogram: a wrapped counter makes the column total fall short
+// of n), a non-finite or > 512 m coordinate, or a footprint of more than 40 960 columns keep the brute-force kernel
+// above (mode[b] = 1); results are identical either way.  (Until round 5 the limit was 65 535 points per CLOUD, which
+// sent every 64-beam less-flat list -- ~100 k points -- to the brute-force kernel: 27 ms per association.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kOdomRange = 512;                         // columns are addressed relative to the cloud's bounding box
 constexpr int kOdomMaxCells = 40960;                    // u16 counters: 80 KB of LDS
@@ -391,7 +393,7 @@ odom_bin_kernel(OdomBinJob job_a, OdomBinJob job_b, int n_pairs) {
   // The first kOdomBinKeep x 1024 points stay in registers for the two later passes (xyz + the packed ring / index word the
   // sorted copy carries): their loads are all requested before the first is used, and the histogram and scatter passes
   // do not go back to memory for them.  Longer clouds run the rest through the streaming loops.
-  int lox = INT32_MAX, loy = INT32_MAX, hix = INT32_MIN, hiy = INT32_MIN, bad = n > 65535 ? 1 : 0;
+  int lox = INT32_MAX, loy = INT32_MAX, hix = INT32_MIN, hiy = INT32_MIN, bad = n >= (1 << 24) ? 1 : 0;
   float kx[kOdomBinKeep], ky[kOdomBinKeep], kz[kOdomBinKeep];
   unsigned kring[(kOdomBinKeep + 3) / 4];                        // four 8-bit ring ids per word
   auto check = [&](float x, float y, float z, int r, int rprev, int i) {
@@ -483,8 +485,12 @@ odom_bin_kernel(OdomBinJob job_a, OdomBinJob job_b, int n_pairs) {
   for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
   if (lane == 63) s_part[wave] = incl;
   __syncthreads();
-  unsigned run = incl - sum;
-  for (int w = 0; w < wave; w++) run += s_part[w];
+  unsigned run = incl - sum, total = 0;
+  for (int w = 0; w < 16; w++) { if (w == wave) run += total; total += s_part[w]; }
+  if (total != (unsigned)n) {                                     // a u16 counter wrapped (every wrap loses 65 535 or 65 536): brute force
+    if (tid == 0) { OdomPairDesc d; d.ox = ox; d.oy = oy; d.W = 0; d.H = 0; desc[b] = d; mode[b] = 1; }
+    return;
+  }
   for (int c = c0; c < c1; c++) { tab[c] = run; run += (s_cnt[c >> 1] >> (16 * (c & 1))) & 0xffffu; }
   if (tid == 0) tab[cells] = (unsigned)n;
   __threadfence_block();
@@ -512,6 +518,171 @@ odom_bin_kernel(OdomBinJob job_a, OdomBinJob job_b, int n_pairs) {
     float4 p = pts[ic];
     p.w = __int_as_float((int)(((unsigned)ring[ic] & 0xffu) << 24 | (unsigned)i));
     place(i < n, p);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same index when the call holds FEW pairs with LONG clouds (the SLAM step's one 64-beam less-flat list: ~100 k points
+// kept the one workgroup above busy for 165 us of the odometry stream while the chip idled): G workgroups per cloud and
+// the counters in the table itself (u32 in global memory: no per-column limit), four launches —
+//   odom_bin_box_kernel      bounding box + the grid's conditions per slice; zeroes the table
+//   odom_bin_count_kernel    box verdict (desc / mode as above), histogram by atomics (one per run of equal columns)
+//   odom_bin_scan_kernel     exclusive scan of the table in place (one workgroup per cloud), a copy as scatter cursors
+//   odom_bin_scatter_kernel  points into their column's run
+// The order inside a column differs from the kernel above and from run to run; the queries' minima are lexicographic
+// (distance, index) keys and do not see it.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct OdomBinSplit {
+  int* part;               // jobs x G x 8: lox, loy, hix, hiy, bad of a slice
+  unsigned* cur;           // jobs x kOdomTabStride scatter cursors
+  int G;
+};
+constexpr int kOdomSplitThreads = 256;
+
+__device__ __forceinline__ bool odom_run_of(bool valid, int c, int lane, int& head_lane, int& len) {
+  const int cc = valid ? c : -1 - lane;
+  const int cprev = __shfl_up(cc, 1);
+  const bool head = lane == 0 || cc != cprev;
+  const unsigned long long hm = __ballot(head);
+  const unsigned long long upto = (2ull << lane) - 1ull;
+  head_lane = 63 - __clzll((long long)(hm & upto));
+  const unsigned long long above = hm & ~upto;
+  len = (above ? __ffsll((long long)above) - 1 : 64) - head_lane;
+  return head;
+}
+
+struct OdomBinSlice { const OdomBinJob* job; int b, job_i, s0, n, i0, i1; };
+__device__ __forceinline__ OdomBinSlice odom_bin_slice(const OdomBinJob& job_a, const OdomBinJob& job_b, int n_pairs, int G) {
+  OdomBinSlice sl;
+  sl.job_i = blockIdx.y;
+  const bool second = sl.job_i >= n_pairs;
+  sl.job = second ? &job_b : &job_a;
+  sl.b = sl.job_i - (second ? n_pairs : 0);
+  sl.s0 = sl.job->off[sl.b]; sl.n = sl.job->off[sl.b + 1] - sl.s0;
+  const int chunk = ((sl.n + G - 1) / G + 63) & ~63;                // whole wavefronts: the run detection works on 64 consecutive points
+  sl.i0 = (int)min((long long)blockIdx.x * chunk, (long long)sl.n); sl.i1 = min(sl.i0 + chunk, sl.n);
+  return sl;
+}
+
+__global__ void __launch_bounds__(kOdomSplitThreads) odom_bin_box_kernel(OdomBinJob job_a, OdomBinJob job_b, int n_pairs, OdomBinSplit sp) {
+  __shared__ int s_red[kOdomSplitThreads / 64][5];
+  const OdomBinSlice sl = odom_bin_slice(job_a, job_b, n_pairs, sp.G);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float4* pts = sl.job->pts + sl.s0;
+  const uint16_t* ring = sl.job->ring + sl.s0;
+  unsigned* tab = sl.job->tab + (size_t)sl.b * kOdomTabStride;
+  for (int c = blockIdx.x * kOdomSplitThreads + tid; c < kOdomTabStride; c += sp.G * kOdomSplitThreads) tab[c] = 0u;
+  int lox = INT32_MAX, loy = INT32_MAX, hix = INT32_MIN, hiy = INT32_MIN, bad = 0;
+  for (int i = sl.i0 + tid; i < sl.i1; i += kOdomSplitThreads) {
+    const float4 p = pts[i];
+    const int r = ring[i], rprev = ring[max(i - 1, 0)];
+    if (!(fabsf(p.x) < (float)kOdomRange && fabsf(p.y) < (float)kOdomRange && fabsf(p.z) < 1e30f) || r >= 256) { bad = 1; continue; }
+    if (i > 0 && rprev > r) bad = 1;
+    const int cx = (int)floorf(p.x), cy = (int)floorf(p.y);
+    lox = min(lox, cx); hix = max(hix, cx); loy = min(loy, cy); hiy = max(hiy, cy);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lox = min(lox, __shfl_xor(lox, o)); loy = min(loy, __shfl_xor(loy, o));
+    hix = max(hix, __shfl_xor(hix, o)); hiy = max(hiy, __shfl_xor(hiy, o)); bad |= __shfl_xor(bad, o);
+  }
+  if (lane == 0) { s_red[wave][0] = lox; s_red[wave][1] = loy; s_red[wave][2] = hix; s_red[wave][3] = hiy; s_red[wave][4] = bad; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < kOdomSplitThreads / 64; w++) {
+      lox = min(lox, s_red[w][0]); loy = min(loy, s_red[w][1]); hix = max(hix, s_red[w][2]); hiy = max(hiy, s_red[w][3]); bad |= s_red[w][4];
+    }
+    int* part = sp.part + ((size_t)sl.job_i * sp.G + blockIdx.x) * 8;
+    part[0] = lox; part[1] = loy; part[2] = hix; part[3] = hiy; part[4] = bad;
+  }
+}
+
+// the box of the whole cloud from the slices' reports: {ox, oy, W, H, bad} (the one-workgroup kernel's rules)
+__device__ __forceinline__ void odom_bin_verdict(const int* __restrict__ part, int G, int n, int* s_box) {
+  int lox = INT32_MAX, loy = INT32_MAX, hix = INT32_MIN, hiy = INT32_MIN, bad = n >= (1 << 24) ? 1 : 0;
+  for (int g = 0; g < G; g++) {
+    lox = min(lox, part[8 * g]); loy = min(loy, part[8 * g + 1]); hix = max(hix, part[8 * g + 2]); hiy = max(hiy, part[8 * g + 3]); bad |= part[8 * g + 4];
+  }
+  int W = 0, H = 0;
+  if (n > 0 && !bad) { W = hix - lox + 1; H = hiy - loy + 1; if ((long long)W * H > kOdomMaxCells) bad = 1; }
+  s_box[0] = lox; s_box[1] = loy; s_box[2] = bad ? 0 : W; s_box[3] = bad ? 0 : H; s_box[4] = bad;
+}
+
+__global__ void __launch_bounds__(kOdomSplitThreads) odom_bin_count_kernel(OdomBinJob job_a, OdomBinJob job_b, int n_pairs, OdomBinSplit sp) {
+  __shared__ int s_box[5];
+  const OdomBinSlice sl = odom_bin_slice(job_a, job_b, n_pairs, sp.G);
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) {
+    odom_bin_verdict(sp.part + (size_t)sl.job_i * sp.G * 8, sp.G, sl.n, s_box);
+    if (blockIdx.x == 0) {
+      OdomPairDesc d; d.ox = s_box[0]; d.oy = s_box[1]; d.W = s_box[2]; d.H = s_box[3];
+      sl.job->desc[sl.b] = d;
+      sl.job->mode[sl.b] = s_box[4] ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (s_box[4] || sl.n == 0) return;
+  const int ox = s_box[0], oy = s_box[1], W = s_box[2];
+  const float4* pts = sl.job->pts + sl.s0;
+  unsigned* tab = sl.job->tab + (size_t)sl.b * kOdomTabStride;
+  for (int i0 = sl.i0 + (tid & ~63); i0 < sl.i1; i0 += kOdomSplitThreads) {
+    const int i = i0 + lane;
+    const bool valid = i < sl.i1;
+    const float4 p = pts[min(i, sl.i1 - 1)];
+    const int c = ((int)floorf(p.y) - oy) * W + ((int)floorf(p.x) - ox);
+    int hl, len;
+    if (odom_run_of(valid, c, lane, hl, len) && valid) atomicAdd(&tab[c], (unsigned)len);
+  }
+}
+
+__global__ void __launch_bounds__(1024) odom_bin_scan_kernel(OdomBinJob job_a, OdomBinJob job_b, int n_pairs, OdomBinSplit sp) {
+  __shared__ unsigned s_part[16];
+  const bool second = (int)blockIdx.x >= n_pairs;
+  const OdomBinJob& job = second ? job_b : job_a;
+  const int b = (int)blockIdx.x - (second ? n_pairs : 0), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = job.off[b + 1] - job.off[b];
+  if (job.mode[b] != 0 || n == 0) return;
+  const OdomPairDesc d = job.desc[b];
+  const int cells = d.W * d.H;
+  unsigned* tab = job.tab + (size_t)b * kOdomTabStride;
+  unsigned* cur = sp.cur + (size_t)blockIdx.x * kOdomTabStride;
+  const int per = (cells + 1023) / 1024;
+  const int c0 = min(tid * per, cells), c1 = min(c0 + per, cells);
+  unsigned sum = 0;
+  for (int c = c0; c < c1; c++) sum += tab[c];
+  unsigned incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  if (lane == 63) s_part[wave] = incl;
+  __syncthreads();
+  unsigned run = incl - sum;
+  for (int w = 0; w < wave; w++) run += s_part[w];
+  for (int c = c0; c < c1; c++) { const unsigned k = tab[c]; tab[c] = run; cur[c] = run; run += k; }
+  if (tid == 0) tab[cells] = (unsigned)n;
+}
+
+__global__ void __launch_bounds__(kOdomSplitThreads) odom_bin_scatter_kernel(OdomBinJob job_a, OdomBinJob job_b, int n_pairs, OdomBinSplit sp) {
+  const OdomBinSlice sl = odom_bin_slice(job_a, job_b, n_pairs, sp.G);
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (sl.job->mode[sl.b] != 0 || sl.n == 0) return;
+  const OdomPairDesc d = sl.job->desc[sl.b];
+  const int ox = d.ox, oy = d.oy, W = d.W;
+  const float4* pts = sl.job->pts + sl.s0;
+  const uint16_t* ring = sl.job->ring + sl.s0;
+  unsigned* cur = sp.cur + (size_t)sl.job_i * kOdomTabStride;
+  float4* sorted = sl.job->sorted + sl.s0;
+  for (int i0 = sl.i0 + (tid & ~63); i0 < sl.i1; i0 += kOdomSplitThreads) {
+    const int i = i0 + lane, ic = min(i, sl.i1 - 1);
+    const bool valid = i < sl.i1;
+    float4 p = pts[ic];
+    p.w = __int_as_float((int)(((unsigned)ring[ic] & 0xffu) << 24 | (unsigned)ic));
+    const int c = ((int)floorf(p.y) - oy) * W + ((int)floorf(p.x) - ox);
+    int hl, len;
+    const bool head = odom_run_of(valid, c, lane, hl, len);
+    unsigned first = 0;
+    if (head && valid) first = atomicAdd(&cur[c], (unsigned)len);
+    first = __shfl(first, hl);
+    if (valid) sorted[first + (unsigned)(lane - hl)] = p;
   }
 }
 

@@ -107,6 +107,44 @@ def test_relative_time_wraps_wherever_they_fall(gpu, oracle):
         _check(f, oracle.extract_features(p, r))
 
 
+def test_ring_split_over_several_workgroups_equals_the_one_workgroup_kernel(oracle, monkeypatch):
+    """A call with few scans splits every scan's ring split over G workgroups (three launches; the SLAM step's one 64-beam
+    sweep kept ONE compute unit busy for 326 us); a batch that fills the chip keeps the one-workgroup kernel.  Every G must
+    write the same bytes -- relative times included, where the oracle comparison allows 1 ulp -- on driver-order, ring-grouped,
+    mid-revolution and reversed clouds, a 64-beam sweep, tiny clouds (most slices empty), an all-invalid cloud and a bad ring."""
+    pts, ring, _, _ = common.scans(1)[0]
+    n = len(pts)
+    order = np.argsort(ring, kind="stable")
+    variants = [(pts, ring), (pts[order], ring[order]), (np.roll(pts, -n // 3, axis=0), np.roll(ring, -n // 3)),
+                (np.roll(pts[order], -(n // 2 + 17), axis=0), np.roll(ring[order], -(n // 2 + 17))), (pts[::-1].copy(), ring[::-1].copy())]
+    world = common.small_world()[0]
+    variants.append(synth.make_scan(world, synth.random_poses(1, synth.SEED + 5)[0], synth.SEED + 6, n_beams=64, n_az=2048, elev=(-24.8, 2.0)))
+    variants.append((pts[:37].copy(), ring[:37].copy()))
+    variants.append((pts[:700].copy(), ring[:700].copy()))
+    nanc = pts[:300].copy(); nanc[:, 0] = np.nan
+    variants.append((nanc, ring[:300].copy()))
+    badr = ring[:500].copy(); badr[123] = 200
+    variants.append((pts[:500].copy(), badr))
+    off = np.cumsum([0] + [len(p) for p, _ in variants]).astype(np.int32)
+    cat_p, cat_r = np.concatenate([p for p, _ in variants]), np.concatenate([r for _, r in variants])
+    results = {}
+    for G in (1, 2, 4, 8, 16):
+        monkeypatch.setenv("MSFL_PREP_SPLIT", str(G))
+        h = capi.Handle(0)
+        try:
+            results[G] = h.extract_features_batch(cat_p, cat_r, off)
+        finally:
+            h.close()
+    assert [f["rc"] for f in results[1]][-2:] == [capi.BAD_ARG, capi.BAD_RING]
+    for G in (2, 4, 8, 16):
+        for f, f1 in zip(results[G], results[1]):
+            assert f["rc"] == f1["rc"]
+            for k in ("full", "ring", "curvature", "label", "sharp", "less_sharp", "flat", "less_flat"):
+                assert np.array_equal(f[k].view(np.uint8), f1[k].view(np.uint8)), (G, k)
+    for (p, r), f in zip(variants[:-2], results[16][:-2]):
+        _check(f, oracle.extract_features(p, r))
+
+
 def test_hand_made_ties_and_gap_breaks(gpu, oracle):
     n = 300
     pts = np.zeros((n, 4), np.float32)

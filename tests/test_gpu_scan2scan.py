@@ -212,6 +212,66 @@ def test_binning_a_cloud_longer_than_its_register_resident_part(gpu, oracle, mon
         assert max(synth.pose_error(poses[b], pose_o)) < TIGHT
 
 
+def test_binning_a_64_beam_sized_cloud_and_a_column_that_overflows_its_counter(gpu, oracle, monkeypatch):
+    """A 64-beam less-flat list holds ~100 k points.  The binning kernel's u16 counters are per COLUMN, so such a cloud
+    still takes the column grid (until round 5 every cloud above 65 535 points fell to the brute-force kernel: 27 ms per
+    association inside the SLAM step); a cloud that really puts more than 65 535 points into one 1 m column is found by
+    the histogram total and keeps the brute-force kernel.  Both must equal the brute-force poses bit for bit, the
+    oracle's within the parity bound.  (What the grid buys shows in the 64-beam SLAM step, profiles/r05_slam64_*: the
+    batch call here is dominated by its 72 MB of host-to-device copies.)"""
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    rng = np.random.default_rng(29)
+    pairs = []
+    for i in range(2):
+        c = [np.copy(a) for a in _clouds(*_pair(oracle, i))]
+        reps = -(-100000 // len(c[2]))
+        pts = [c[2]]
+        for _ in range(reps - 1):
+            q = np.copy(c[2]); q[:, :3] += rng.normal(0, 0.03, (len(q), 3)).astype(np.float32); pts.append(q)
+        cat, ring = np.concatenate(pts)[:100000], np.concatenate([c[3]] * reps)[:100000]
+        if i == 1:                                                # 70 000 of them inside one column: the counter wraps
+            cat[:70000, :2] = (np.array([3.5, 2.5]) + rng.uniform(-0.45, 0.45, (70000, 2))).astype(np.float32)
+        order = np.argsort(ring, kind="stable")
+        c[2], c[3] = np.ascontiguousarray(cat[order]), np.ascontiguousarray(ring[order])
+        assert len(c[2]) == 100000
+        pairs.append(c)
+    batch = [pairs[0]] * 38 + [pairs[1]] * 2
+    guesses = np.stack([ident] * 40)
+    guesses[:, 0] = np.linspace(-0.4, 0.4, 40)
+    sets = _batch_sets(batch)
+    poses, status, info = gpu.match_scan2scan_batch(sets, guesses, want_info=True)
+    assert np.all(status[:38] == 0)
+    monkeypatch.setenv("MSFL_ODOM_BRUTE", "1")
+    h2 = capi.Handle(0)
+    try:
+        poses2, status2, _ = h2.match_scan2scan_batch(sets, guesses)
+    finally:
+        h2.close()
+    assert np.array_equal(status, status2) and np.array_equal(poses, poses2)
+    # the index build with 64 workgroups per cloud (what a call with one to four such pairs takes: the SLAM step)
+    monkeypatch.delenv("MSFL_ODOM_BRUTE")
+    monkeypatch.setenv("MSFL_ODOM_BIN_SPLIT", "1")
+    h3 = capi.Handle(0)
+    try:
+        poses3, status3, _ = h3.match_scan2scan_batch(sets, guesses)
+        few = _batch_sets(batch[37:40])                           # three pairs: the split by itself (MSFL_ODOM_BIN_SPLIT unset below)
+        monkeypatch.delenv("MSFL_ODOM_BIN_SPLIT")
+        h4 = capi.Handle(0)
+        try:
+            poses4, status4, _ = h4.match_scan2scan_batch(few, guesses[37:40])
+        finally:
+            h4.close()
+    finally:
+        h3.close()
+    assert np.array_equal(status, status3) and np.array_equal(poses, poses3)
+    assert np.array_equal(status[37:40], status4) and np.array_equal(poses[37:40], poses4)
+    for b in (0, 39):
+        rc, pose_o, info_o = oracle.match_scan2scan(*batch[b], guesses[b])
+        assert rc == status[b] and list(info[b].n_plane) == list(info_o.n_plane)
+        if rc == 0:
+            assert max(synth.pose_error(poses[b], pose_o)) < TIGHT
+
+
 def test_empty_and_nonfinite_clouds(gpu, oracle):
     """Empty previous-scan clouds (the reference never guards them, odometry_scan_matcher.cc:57-61) give
     'too few correspondences'; NaN points must not poison neighbours, on any of the three kernels."""
@@ -282,6 +342,13 @@ def test_randomised_pairs_three_paths_agree(gpu, oracle, seed, monkeypatch):
     guesses = np.stack([guess] * 45)
     poses, status, _ = gpu.match_scan2scan_batch(_batch_sets(pairs), guesses)
     assert np.all(status == s) and all(np.array_equal(poses[b], pose_g) for b in (0, 17, 44))
+    monkeypatch.setenv("MSFL_ODOM_BIN_SPLIT", "1")                # the index build of few long clouds: 64 workgroups per cloud
+    hs = capi.Handle(0)
+    try:
+        poses_s, status_s, _ = hs.match_scan2scan_batch(_batch_sets(pairs), guesses)
+    finally:
+        hs.close()
+    assert np.array_equal(status_s, status) and np.array_equal(poses_s, poses)
 
 
 def test_large_gate_keeps_the_batch_path_exact(oracle):

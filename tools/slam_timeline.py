@@ -40,7 +40,7 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Stream_Id"], short(r["Kernel_Name"])))
     rows.sort()
     # stream roles: by the marker kernels that only ever run on one of them
-    marker = {"extract_prepare_kernel": "odometry", "slam_result_kernel": "mapping (surf side)", "voxel_cloud_lds_kernel<4, 512, false>": "voxel filters"}
+    marker = {"extract_prepare_kernel": "odometry", "extract_prepare_count_kernel": "odometry", "slam_result_kernel": "mapping (surf side)", "voxel_cloud_lds_kernel<4, 512, false>": "voxel filters"}
     role = {}
     for want in ("odometry", "mapping (surf side)", "voxel filters"):     # markers first: a stream has one role
         for s, e, st, n in rows:
@@ -64,6 +64,8 @@ def main():
         start_marker = first_of_scan.get(name)
         if start_marker is None:
             continue
+        if name == "odometry" and any(r[3] == "extract_prepare_count_kernel" for r in lst):
+            start_marker = "extract_prepare_count_kernel"           # round 5: the ring split of a one-scan call is three launches
         scans, cur, seen_pose = [], None, 0
         for r in lst:
             is_start = r[3] == start_marker
