@@ -241,10 +241,11 @@ grid_emit_scan_kernel(const int* __restrict__ stamp, const int* __restrict__ cel
 // makes them, then a bitonic sort in LDS of (key, ordinal) — the ordinal as the tie-break is what a stable sort gives.
 constexpr int kGridSortSmall = 2048;
 constexpr int kGridOneBlockMax = 1 << 17;          // lists / cell tables up to this size take the one-workgroup forms
+constexpr int kGridTouchOneBlockMax = 1 << 15;     // the touched-cell list of an insert: longer point lists (a 64-beam less-flat list) take the flag / scan / list launches
 __global__ void __launch_bounds__(1024)
 grid_key_sort_small_kernel(const float4* __restrict__ pts, int n_cap, const int* __restrict__ n_dev, const double* __restrict__ pose,
                            float4* __restrict__ xf, GridStoreDesc d, unsigned long long* __restrict__ skeys, int* __restrict__ svals,
-                           GridState* __restrict__ st) {
+                           float4* __restrict__ xs, GridState* __restrict__ st) {
   __shared__ unsigned long long s_key[kGridSortSmall];
   __shared__ unsigned short s_val[kGridSortSmall];
   const int n = grid_dev_n(n_cap, n_dev);
@@ -274,7 +275,23 @@ grid_key_sort_small_kernel(const float4* __restrict__ pts, int n_cap, const int*
       if (a_after_b == up) { s_key[lo] = kb; s_key[hi] = ka; s_val[lo] = vb; s_val[hi] = va; }
       __syncthreads();
     }
-  for (int i = threadIdx.x; i < n_cap; i += 1024) { skeys[i] = s_key[i]; svals[i] = (int)s_val[i]; }
+  __threadfence_block();                                           // xf (written above) is read back below by other threads of the workgroup
+  __syncthreads();
+  const float4* src = pose ? xf : pts;
+  for (int i = threadIdx.x; i < n_cap; i += 1024) {
+    skeys[i] = s_key[i]; svals[i] = (int)s_val[i];
+    if (i < n && (int)s_val[i] < n_cap) xs[i] = src[s_val[i]];                               // the points in sorted order (see grid_gather_sorted_kernel)
+  }
+}
+
+// The new points in sorted order: a cell's new points are then one contiguous piece [t_ns, t_ns + n_new) and a voxel run inside it
+// consecutive addresses, so the rebuild reads a point with ONE load that coalesces across a wavefront instead of the
+// index load -> scattered point load chain (two dependent latencies per entry on the longest voxel run of the slowest cell).
+__global__ void __launch_bounds__(256)
+grid_gather_sorted_kernel(const float4* __restrict__ xf, const int* __restrict__ svals, int n_cap, const int* __restrict__ n_dev,
+                          float4* __restrict__ xs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < grid_dev_n(n_cap, n_dev)) xs[i] = xf[svals[i]];
 }
 
 __device__ __forceinline__ int grid_find_cell(const unsigned long long* __restrict__ cell_keys, int n_cells, unsigned long long key) {
@@ -294,7 +311,15 @@ __device__ __forceinline__ int grid_lower_bound(const unsigned long long* __rest
 }
 
 // LDS capacities of the two rebuild instantiations (entries = old + new points of one cell, padded to a power of two)
-constexpr int kGridSmallCap = 2048;               // 256 threads, 16 KB: the common cell (tens to hundreds of points)
+#ifndef MSFL_GRID_SMALL_CAP
+#define MSFL_GRID_SMALL_CAP 4096
+#endif
+#ifndef MSFL_GRID_SMALL_THREADS
+#define MSFL_GRID_SMALL_THREADS 512
+#endif
+constexpr int kGridSmallCap = MSFL_GRID_SMALL_CAP;         // the LDS form: 512 threads, 32 KB of sort entries + 64 KB of points (round 5: 256 threads / 2 048
+                                                           // entries left the 2 000 - 4 000-entry cells of a 64-beam sweep to the large form)
+constexpr int kGridSmallThreads = MSFL_GRID_SMALL_THREADS;
 constexpr int kGridLargeCap = 16384;              // 1024 threads, 128 KB; beyond that the sort runs in a global scratch slab
 __host__ __device__ __forceinline__ int grid_pow2_at_least(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
@@ -359,19 +384,25 @@ __device__ __forceinline__ void grid_bitonic(unsigned long long* __restrict__ s,
   }
 }
 
+#ifdef MSFL_GRID_PROF
+__device__ unsigned long long g_grid_prof[1024 * 8];      // profile build: per touched cell, phase durations in 10 ns ticks
+#endif
 template <int THREADS, int LDS_CAP, bool LARGE>
 __global__ void __launch_bounds__(THREADS)
 grid_rebuild_kernel(const float4* __restrict__ pool_in, float4* __restrict__ pool_out, const int* __restrict__ cell_start,
-                    const int* __restrict__ cell_cnt, const float4* __restrict__ xf, const unsigned long long* __restrict__ skeys,
-                    const int* __restrict__ svals, const unsigned long long* __restrict__ t_key, const int* __restrict__ t_ns,
+                    const int* __restrict__ cell_cnt, const float4* __restrict__ xs, const unsigned long long* __restrict__ skeys,
+                    const unsigned long long* __restrict__ t_key, const int* __restrict__ t_ns,
                     const int* __restrict__ t_old, const int* __restrict__ t_woff, int* __restrict__ t_cnt, GridStoreDesc d,
                     GridState* __restrict__ st) {
   __shared__ unsigned long long s_ent[LDS_CAP];
-  __shared__ int s_wsum[THREADS / 64];
-  __shared__ int s_carry, s_unsorted;
-  constexpr int kLongRun = 16, kLongCap = LDS_CAP / 16 > 1024 ? 1024 : LDS_CAP / 16;      // runs the head thread hands to a wavefront
+  __shared__ int s_hcnt[LDS_CAP / 64];                  // run heads per (chunk, wavefront) of a piece, then their exclusive scan
+  constexpr int kLongCap = LDS_CAP / 16 > 1024 ? 1024 : LDS_CAP / 16;      // runs the head thread hands to a wavefront
   __shared__ int s_long[kLongCap][3];
   __shared__ int s_nlong;
+  static_assert(LARGE || LDS_CAP <= 32768, "s_run packs a run as (length << 16 | first entry)");
+  __shared__ float4 s_pts[LARGE ? 1 : LDS_CAP];         // the LDS form: the cell's points in entry order
+  __shared__ unsigned s_run[LARGE ? 1 : LDS_CAP];       //               its runs by rank: length << 16 | first entry
+  __shared__ int s_carry, s_unsorted;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = st->n_touched;
   if (LARGE && st->n_big == 0) return;
@@ -386,6 +417,9 @@ grid_rebuild_kernel(const float4* __restrict__ pool_in, float4* __restrict__ poo
     }
     const int P = grid_pow2_at_least(E);
     const int woff = t_woff[t];
+#ifdef MSFL_GRID_PROF
+    unsigned long long tq[6]; tq[0] = wall_clock64();
+#endif
     // entries beyond the LDS capacity (LARGE only): the sort runs in the scratch half of the cell's slab
     unsigned long long* ent = s_ent;
     if (LARGE && P > LDS_CAP) ent = reinterpret_cast<unsigned long long*>(pool_out + woff + E);
@@ -410,80 +444,161 @@ grid_rebuild_kernel(const float4* __restrict__ pool_in, float4* __restrict__ poo
       ent[i] = key;
     }
     __syncthreads();
+#ifdef MSFL_GRID_PROF
+    tq[1] = wall_clock64();
+#endif
     grid_bitonic<THREADS>(ent, P, s_unsorted ? 2 : P);
-    // voxel runs: heads, their ranks (block scan over chunks of THREADS entries), one thread per head walks its run.
-    // Round 5: a run of more than kLongRun entries is not walked by its head's thread (one dependent index -> point gather per entry: a
-    // 0.4 m voxel on a corridor wall 1.5 m from the sensor receives hundreds of points per scan and its thread's chain was the whole
-    // kernel: 279 us per insert) but queued and summed by a whole wavefront afterwards: 64 entries per coalesced gather, then the same
-    // sequential f32 additions in the same order through scalar broadcasts (bit-identical); short runs request four points at a time.
+#ifdef MSFL_GRID_PROF
+    tq[2] = wall_clock64();
+#endif
+    // voxel runs -> one centroid per run: f32 sums in entry order (old points first, then new ones in arrival order), as pcl's
+    // CentroidPoint accumulates them.  The entries are walked in pieces of LDS_CAP (one piece unless the cell is beyond the LDS
+    // form).  Pass 1 counts the run heads of every (chunk of THREADS entries, wavefront); one wavefront scans those counts; pass 2
+    // recomputes a head's rank from them and sums its run -- no barrier between chunks, so the gathers of all short runs of the
+    // cell are in flight together (rounds 3-5a ranked and summed chunk by chunk, three barriers each: 22 us of the 56 that a
+    // 1 800-entry cell of a 64-beam sweep took).
+    //   run of up to kThreadRun entries: its head's thread, four gathers in flight (the new points of a run are consecutive in xs)
+    //   longer run (a 0.4 m voxel on a corridor wall 1.5 m from the sensor receives hundreds of points per scan; one thread chasing
+    //   them set the whole kernel: 279 us per insert): queued, summed by a wavefront afterwards -- 64 entries per coalesced
+    //   gather, the next 64 (of this run or of the wavefront's next run) loading meanwhile, then the same sequential additions
+    //   through scalar broadcasts (bit-identical).
+    // Rejected (round 5, docs/rejected_experiments.md): every run on a wavefront's scalar-broadcast walk (one useful addition per
+    // 64-lane instruction: 2x slower on 16-beam cells), head threads taking runs of up to 64 entries (their gathers serialise).
+    //   The LDS form (!LARGE) first copies the cell's points into LDS in entry order -- every thread's loads in flight together,
+    //   one memory latency for the whole cell -- lists the runs by rank, and run r is summed by thread r from LDS (four reads in
+    //   flight, all lanes at work; a wavefront's scalar-broadcast walk spends a 64-lane instruction per addition and measured
+    //   ~4 us per 64 entries even from LDS).
     float4* out = pool_out + woff;
-    auto entry_point = [&](int j) __attribute__((always_inline)) {
+    auto entry_global = [&](int j) __attribute__((always_inline)) {
       const int ord = (int)(unsigned)ent[j];
-      return ord < n_old ? pool_in[o_start + ord] : xf[svals[ns + ord - n_old]];
+      return ord < n_old ? pool_in[o_start + ord] : xs[ns + ord - n_old];
     };
+    constexpr int kWaves = THREADS / 64, kPer = LDS_CAP / THREADS, kThreadRun = 16;
+    if (!LARGE) {
+      float4 pv[kPer];
+#pragma unroll
+      for (int c = 0; c < kPer; c++) { const int i = c * THREADS + tid; if (i < E) pv[c] = entry_global(i); }
+#pragma unroll
+      for (int c = 0; c < kPer; c++) { const int i = c * THREADS + tid; if (i < E) s_pts[i] = pv[c]; }
+    }
+    auto entry_point = [&](int j) __attribute__((always_inline)) { return LARGE ? entry_global(j) : s_pts[j]; };
     if (tid == 0) s_nlong = 0;
-    for (int base = 0; base < E; base += THREADS) {
-      const int i = base + tid;
-      unsigned v = 0; bool head = false;
-      if (i < E) {
-        v = (unsigned)(ent[i] >> 32);
-        head = i == 0 || v != (unsigned)(ent[i - 1] >> 32);
+    int carry = 0;
+    for (int sb = 0; sb < E; sb += LDS_CAP) {
+      const int se = min(E, sb + LDS_CAP);
+#pragma unroll
+      for (int c = 0; c < kPer; c++) {
+        const int i = sb + c * THREADS + tid;
+        const bool head = i < se && (i == 0 || (unsigned)(ent[i] >> 32) != (unsigned)(ent[i - 1] >> 32));
+        const unsigned long long hm = __ballot(head);
+        if (lane == 0) s_hcnt[c * kWaves + wave] = __popcll(hm);
       }
-      const unsigned long long hm = __ballot(head);
-      const int before = __popcll(hm & ((1ull << lane) - 1ull));
-      if (lane == 0) s_wsum[wave] = __popcll(hm);
       __syncthreads();
-      int r = s_carry + before;
-      for (int w = 0; w < wave; w++) r += s_wsum[w];
-      if (head) {
-        // end of the run: the entries are sorted, so gallop (1, 2, 4, ... entries ahead) and bisect — a run of 500 entries costs ~18
-        // dependent LDS reads instead of 500 (the workgroup's barrier waits for the longest of its heads)
-        int lo = i, step = 1;
-        while (lo + step < E && (unsigned)(ent[lo + step] >> 32) == v) { lo += step; step <<= 1; }
-        int j = min(lo + step, E);
-        while (j - lo > 1) { const int mid = (lo + j) >> 1; if ((unsigned)(ent[mid] >> 32) == v) lo = mid; else j = mid; }
-        const int L = j - i;
-        int slot = -1;
-        if (L > kLongRun) { slot = atomicAdd(&s_nlong, 1); if (slot >= kLongCap) slot = -1; }
-        if (slot >= 0) { s_long[slot][0] = r; s_long[slot][1] = i; s_long[slot][2] = L; }
-        else {
-          float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
-          for (int q = i; q < j; q += 4) {                                 // four gathers in flight, added in run order
-            const float4 p0 = entry_point(q), p1 = entry_point(min(q + 1, j - 1)), p2 = entry_point(min(q + 2, j - 1)), p3 = entry_point(min(q + 3, j - 1));
-            sx += p0.x; sy += p0.y; sz += p0.z; sw += p0.w;
-            if (q + 1 < j) { sx += p1.x; sy += p1.y; sz += p1.z; sw += p1.w; }
-            if (q + 2 < j) { sx += p2.x; sy += p2.y; sz += p2.z; sw += p2.w; }
-            if (q + 3 < j) { sx += p3.x; sy += p3.y; sz += p3.z; sw += p3.w; }
+      if (wave == 0) {                                                     // exclusive scan of the kPer x kWaves counts (chunk-major = entry order)
+        constexpr int kCnt = kPer * kWaves, kEach = (kCnt + 63) / 64;
+        int v[kEach], sum = 0;
+#pragma unroll
+        for (int u = 0; u < kEach; u++) { const int k = lane * kEach + u; v[u] = k < kCnt ? s_hcnt[k] : 0; sum += v[u]; }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(incl, o); if (lane >= o) incl += t2; }
+        int run = incl - sum;
+#pragma unroll
+        for (int u = 0; u < kEach; u++) { const int k = lane * kEach + u; if (k < kCnt) s_hcnt[k] = run; run += v[u]; }
+        if (lane == 63) s_carry = incl;                                    // runs that start in this piece
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < kPer; c++) {
+        const int i = sb + c * THREADS + tid;
+        if (sb + c * THREADS >= se) break;                                 // uniform
+        unsigned v = 0; bool head = false;
+        if (i < se) { v = (unsigned)(ent[i] >> 32); head = i == 0 || v != (unsigned)(ent[i - 1] >> 32); }
+        const unsigned long long hm = __ballot(head);
+        if (head) {
+          const int r = carry + s_hcnt[c * kWaves + wave] + __popcll(hm & ((1ull << lane) - 1ull));
+          // end of the run: the entries are sorted, so gallop (1, 2, 4, ... entries ahead) and bisect
+          int lo = i, step = 1;
+          while (lo + step < E && (unsigned)(ent[lo + step] >> 32) == v) { lo += step; step <<= 1; }
+          int j = min(lo + step, E);
+          while (j - lo > 1) { const int mid = (lo + j) >> 1; if ((unsigned)(ent[mid] >> 32) == v) lo = mid; else j = mid; }
+          const int L = j - i;
+          int slot = -1;
+          if (LARGE && L > kThreadRun) { slot = atomicAdd(&s_nlong, 1); if (slot >= kLongCap) slot = -1; }
+          if (!LARGE) s_run[r] = ((unsigned)L << 16) | (unsigned)i;        // the LDS form: the runs listed by rank, summed below
+          else if (slot >= 0) { s_long[slot][0] = r; s_long[slot][1] = i; s_long[slot][2] = L; }
+          else {
+            float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+            for (int q = i; q < j; q += 4) {                               // four gathers in flight, added in run order
+              const float4 p0 = entry_point(q), p1 = entry_point(min(q + 1, j - 1)), p2 = entry_point(min(q + 2, j - 1)), p3 = entry_point(min(q + 3, j - 1));
+              sx += p0.x; sy += p0.y; sz += p0.z; sw += p0.w;
+              if (q + 1 < j) { sx += p1.x; sy += p1.y; sz += p1.z; sw += p1.w; }
+              if (q + 2 < j) { sx += p2.x; sy += p2.y; sz += p2.z; sw += p2.w; }
+              if (q + 3 < j) { sx += p3.x; sy += p3.y; sz += p3.z; sw += p3.w; }
+            }
+            const float cnt = (float)L;
+            out[r] = make_float4(sx / cnt, sy / cnt, sz / cnt, sw / cnt);
           }
-          const float c = (float)L;
-          out[r] = make_float4(sx / c, sy / c, sz / c, sw / c);
         }
       }
-      __syncthreads();
-      if (tid == THREADS - 1) s_carry = r + (head ? 1 : 0);
-      __syncthreads();
+      carry += s_carry;
+      __syncthreads();                                                     // s_hcnt / s_carry are rewritten by the next piece
     }
-    __syncthreads();
+    if (!LARGE) {
+      // the LDS form: run r to thread r (the run heads are sparse in the entries -- one in ~30 on a 64-beam sweep's cell -- so summing
+      // them where they were found left two or three lanes of a wavefront at work, eight chunks in turn: 48 us on a 4 000-entry cell)
+      for (int r = tid; r < carry; r += THREADS) {
+        const unsigned w = s_run[r];
+        const int i = (int)(w & 0xffffu), L = (int)(w >> 16), j = i + L;
+        float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+        for (int q = i; q < j; q += 4) {                                   // four LDS reads in flight, added in run order
+          const float4 p0 = s_pts[q], p1 = s_pts[min(q + 1, j - 1)], p2 = s_pts[min(q + 2, j - 1)], p3 = s_pts[min(q + 3, j - 1)];
+          sx += p0.x; sy += p0.y; sz += p0.z; sw += p0.w;
+          if (q + 1 < j) { sx += p1.x; sy += p1.y; sz += p1.z; sw += p1.w; }
+          if (q + 2 < j) { sx += p2.x; sy += p2.y; sz += p2.z; sw += p2.w; }
+          if (q + 3 < j) { sx += p3.x; sy += p3.y; sz += p3.z; sw += p3.w; }
+        }
+        const float cnt = (float)L;
+        out[r] = make_float4(sx / cnt, sy / cnt, sz / cnt, sw / cnt);
+      }
+    }
+#ifdef MSFL_GRID_PROF
+    tq[3] = wall_clock64();
+#endif
     {
       const int n_long = min(s_nlong, kLongCap);
-      for (int q = wave; q < n_long; q += THREADS / 64) {
-        const int r = s_long[q][0], i0 = s_long[q][1], L = s_long[q][2];
-        float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
-        float4 p = entry_point(i0 + min(lane, L - 1));
-        for (int c0 = 0; c0 < L; c0 += 64) {
-          const float4 pc = p;
-          const int m = min(64, L - c0);
-          if (c0 + 64 < L) p = entry_point(i0 + c0 + 64 + min(lane, L - c0 - 64 - 1));      // the next 64 entries load while these are summed
-          for (int e = 0; e < m; e++) {
-            sx += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.x), e)); sy += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.y), e));
-            sz += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.z), e)); sw += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.w), e));
-          }
+      int q = wave, c0 = 0;
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < n_long) p = entry_point(s_long[q][1] + min(lane, s_long[q][2] - 1));
+      float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+      while (q < n_long) {
+        const int r = s_long[q][0], L = s_long[q][2];
+        const float4 pc = p;
+        const int m = min(64, L - c0);
+        int nq = q, nc0 = c0 + 64;
+        if (nc0 >= L) { nq = q + kWaves; nc0 = 0; }
+        if (nq < n_long) { const int nL = s_long[nq][2]; p = entry_point(s_long[nq][1] + nc0 + min(lane, nL - nc0 - 1)); }
+        for (int e = 0; e < m; e++) {
+          sx += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.x), e)); sy += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.y), e));
+          sz += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.z), e)); sw += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc.w), e));
         }
-        if (lane == 0) { const float c = (float)L; out[r] = make_float4(sx / c, sy / c, sz / c, sw / c); }
+        if (nc0 == 0) {                                                    // the run is complete
+          if (lane == 0) { const float cnt = (float)L; out[r] = make_float4(sx / cnt, sy / cnt, sz / cnt, sw / cnt); }
+          sx = 0.f; sy = 0.f; sz = 0.f; sw = 0.f;
+        }
+        q = nq; c0 = nc0;
       }
     }
     __syncthreads();
-    if (tid == 0) { const int R = s_carry; t_cnt[t] = R; atomicAdd(&st->delta_points, R - n_old); }
+#ifdef MSFL_GRID_PROF
+    tq[4] = wall_clock64();
+    if (tid == 0 && t < 1024) {
+      unsigned long long* q = g_grid_prof + (size_t)t * 8;
+      q[0] = (unsigned long long)E | ((unsigned long long)THREADS << 32); q[1] = tq[1] - tq[0]; q[2] = tq[2] - tq[1]; q[3] = tq[3] - tq[2]; q[4] = tq[4] - tq[3];
+      q[5] = tq[0]; q[6] = tq[4]; q[7] = (unsigned long long)carry | ((unsigned long long)blockIdx.x << 32);
+    }
+#endif
+    if (tid == 0) { const int R = carry; t_cnt[t] = R; atomicAdd(&st->delta_points, R - n_old); }
     __syncthreads();
   }
 }

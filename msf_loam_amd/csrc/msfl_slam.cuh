@@ -260,19 +260,21 @@ slam_full_cloud_kernel(const SlamImuDev* __restrict__ imu, const double* __restr
 // one centroid per index run, f32 sums in arrival order.  Every kernel acts only when the list was refused (flag 4) and
 // sizes itself from the device-side count; the host enqueues the chain when the scan capacity allows such a list at all.
 struct VoxBigDesc { int mn[3]; int d[3]; int n; int active; };
+constexpr int kVoxBigBoxGroups = 64;          // workgroups of the bounding-box pass (one kept a compute unit busy for 67 us on 100 k points)
+struct VoxBigPart { int mn[3]; int mx[3]; int bad; int pad; };
 
-__global__ void __launch_bounds__(1024)
+// slice g of the list: per-slice box + verdict (0 fine, 1 leaf too small, 3 non-finite point) -> part[g]
+__global__ void __launch_bounds__(256)
 vox_big_bbox_kernel(const float4* __restrict__ pts, const int* __restrict__ idx, const int* __restrict__ count, int n_cap, float inv_leaf,
-                    int* __restrict__ flag, int* __restrict__ m_out, VoxBigDesc* __restrict__ desc) {
+                    const int* __restrict__ flag, VoxBigPart* __restrict__ part) {
   __shared__ int s_mn[3], s_mx[3], s_bad;
   const int tid = threadIdx.x;
-  const bool active = *flag == 4;
-  if (!active) { if (tid == 0) desc->active = 0; return; }
+  if (*flag != 4) return;
   const int n = min(max(*count, 0), n_cap);
   if (tid == 0) { for (int a = 0; a < 3; a++) { s_mn[a] = INT32_MAX; s_mx[a] = INT32_MIN; } s_bad = 0; }
   __syncthreads();
   int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN}, bad = 0;
-  for (int k = tid; k < n; k += 1024) {
+  for (int k = blockIdx.x * 256 + tid; k < n; k += kVoxBigBoxGroups * 256) {
     const float4 p = pts[idx ? idx[k] : k];
     const float f0 = floorf(p.x * inv_leaf), f1 = floorf(p.y * inv_leaf), f2 = floorf(p.z * inv_leaf);
     if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { bad = 3; continue; }
@@ -284,13 +286,35 @@ vox_big_bbox_kernel(const float4* __restrict__ pts, const int* __restrict__ idx,
   if (bad) atomicMax(&s_bad, bad);
   __syncthreads();
   if (tid == 0) {
-    int f = s_bad;
+    VoxBigPart q;
+    for (int a = 0; a < 3; a++) { q.mn[a] = s_mn[a]; q.mx[a] = s_mx[a]; }
+    q.bad = s_bad; q.pad = 0;
+    part[blockIdx.x] = q;
+  }
+}
+
+// the slices' boxes -> the list's descriptor; a list refused for good (non-finite point, leaf too small) or empty gets its final flag here
+__global__ void __launch_bounds__(64)
+vox_big_desc_kernel(const VoxBigPart* __restrict__ part, const int* __restrict__ count, int n_cap, int* __restrict__ flag, int* __restrict__ m_out,
+                    VoxBigDesc* __restrict__ desc) {
+  static_assert(kVoxBigBoxGroups == 64, "one slice per lane");
+  const int lane = threadIdx.x;
+  if (*flag != 4) { if (lane == 0) desc->active = 0; return; }
+  const VoxBigPart q = part[lane];
+  int mn[3] = {q.mn[0], q.mn[1], q.mn[2]}, mx[3] = {q.mx[0], q.mx[1], q.mx[2]}, f = q.bad;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int a = 0; a < 3; a++) { mn[a] = min(mn[a], __shfl_xor(mn[a], o)); mx[a] = max(mx[a], __shfl_xor(mx[a], o)); }
+    f = max(f, __shfl_xor(f, o));
+  }
+  if (lane == 0) {
+    const int n = min(max(*count, 0), n_cap);
     long long cells = 1;
-    for (int a = 0; a < 3 && !f; a++) { cells *= (long long)s_mx[a] - s_mn[a] + 1; if (cells > 0x7fffffffLL) f = 1; }   // pcl: leaf too small
-    for (int a = 0; a < 3; a++) { desc->mn[a] = s_mn[a]; desc->d[a] = s_mx[a] - s_mn[a] + 1; }
+    for (int a = 0; a < 3 && !f && n > 0; a++) { cells *= (long long)mx[a] - mn[a] + 1; if (cells > 0x7fffffffLL) f = 1; }   // pcl: leaf too small
+    for (int a = 0; a < 3; a++) { desc->mn[a] = mn[a]; desc->d[a] = mx[a] - mn[a] + 1; }
     desc->n = n;
     desc->active = (f == 0 && n > 0) ? 1 : 0;
-    if (f != 0 || n == 0) { *flag = f; *m_out = 0; }           // refused for good (non-finite point, leaf too small) or empty
+    if (f != 0 || n == 0) { *flag = f; *m_out = 0; }
   }
 }
 
@@ -314,25 +338,71 @@ vox_big_head_kernel(const unsigned* __restrict__ skeys, int n_cap, const VoxBigD
   head[k] = (desc->active && k < desc->n && (k == 0 || skeys[k] != skeys[k - 1])) ? 1 : 0;
 }
 
+// One centroid per run of equal keys: f32 sums in arrival order (the sort is stable), as pcl's CentroidPoint accumulates them.
+// The run's head thread finds its end in the sorted keys (galloping, then bisection); a run of up to 16 points is summed by that
+// thread with its index loads requested together and four gathers in flight; a longer one (a 64-beam sweep puts hundreds of
+// returns into a near voxel: one thread chasing them one gather at a time set the kernel's 62 us) is queued and summed by a
+// wavefront: 64 coalesced index loads and gathers per step, then 64 scalar-broadcast adds in order.
+constexpr int kVoxBigShortRun = 16;
 __global__ void __launch_bounds__(256)
 vox_big_centroid_kernel(const float4* __restrict__ pts, const int* __restrict__ idx, const unsigned* __restrict__ skeys,
                         const unsigned* __restrict__ svals, const int* __restrict__ head, const int* __restrict__ pos, int n_cap,
                         const VoxBigDesc* __restrict__ desc, float4* __restrict__ out, int* __restrict__ m_out, int* __restrict__ flag) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ int s_long[256][2];
+  __shared__ int s_nlong;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.x * blockDim.x + tid;
   if (!desc->active) return;
   const int n = desc->n;
+  if (tid == 0) s_nlong = 0;
+  __syncthreads();
   if (k == n - 1) { *m_out = pos[k]; *flag = 0; }
-  if (k >= n || !head[k]) return;
-  const unsigned key = skeys[k];
-  float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
-  int j = k;
-  for (; j < n && skeys[j] == key; j++) {
-    const int a = (int)svals[j];
-    const float4 p = pts[idx ? idx[a] : a];
-    sx += p.x; sy += p.y; sz += p.z; sw += p.w;                  // CentroidPoint accumulators (f32), arrival order (stable sort)
+  if (k < n && head[k]) {
+    const unsigned key = skeys[k];
+    int lo = k, step = 1;                                    // skeys[lo] == key; gallop to the first position that is not
+    while (lo + step < n && skeys[lo + step] == key) { lo += step; step <<= 1; }
+    int hi = min(lo + step, n);                              // skeys[hi] != key (or hi == n)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (skeys[mid] == key) lo = mid; else hi = mid; }
+    const int len = hi - k;
+    if (len <= kVoxBigShortRun) {
+      int a[kVoxBigShortRun];
+#pragma unroll
+      for (int u = 0; u < kVoxBigShortRun; u++) { const int v = (int)svals[min(k + u, n - 1)]; a[u] = idx ? idx[v] : v; }
+      float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+#pragma unroll
+      for (int u0 = 0; u0 < kVoxBigShortRun; u0 += 4) {
+        if (u0 >= len) break;
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = pts[a[u0 + u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (u0 + u < len) { sx += p[u].x; sy += p[u].y; sz += p[u].z; sw += p[u].w; }
+      }
+      const float c = (float)len;
+      out[pos[k] - 1] = make_float4(sx / c, sy / c, sz / c, sw / c);
+    } else {
+      const int q = atomicAdd(&s_nlong, 1);
+      s_long[q][0] = k; s_long[q][1] = len;
+    }
   }
-  const float c = (float)(j - k);
-  out[pos[k] - 1] = make_float4(sx / c, sy / c, sz / c, sw / c);
+  __syncthreads();
+  const int nl = s_nlong;
+  for (int q = wave; q < nl; q += 4) {
+    const int k0 = s_long[q][0], len = s_long[q][1];
+    float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+    for (int base = 0; base < len; base += 64) {
+      const int cnt = min(64, len - base);
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < cnt) { const int v = (int)svals[k0 + base + lane]; p = pts[idx ? idx[v] : v]; }
+      for (int t = 0; t < cnt; t++) {
+        sx += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), t));
+        sy += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), t));
+        sz += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.z), t));
+        sw += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.w), t));
+      }
+    }
+    if (lane == 0) { const float c = (float)len; out[pos[k0] - 1] = make_float4(sx / c, sy / c, sz / c, sw / c); }
+  }
 }
 
 }  // namespace msfl

@@ -162,8 +162,8 @@ def test_kitti_layout_replays_through_the_device_resident_slam_step(oracle, tmp_
     """A sequence written in KITTI layout (velodyne/*.bin without ring ids, times.txt, poses), read back through
     dataset.KittiSequence (rings re-derived from elevation) and fed to msfl_slam_add_scan scan by scan: the poses must
     equal the oracle-driven odometry + mapping loop on the same clouds.  64 beams: a ~100 k-point less-flat list is beyond
-    what the one-workgroup voxel filter and the scan-to-scan column grid address (65 535 points), so this also covers the
-    point-sort voxel form and the brute-force association of the SLAM step."""
+    what the one-workgroup voxel filters address (65 535 points), so this also covers the point-sort voxel form, and the several-
+    workgroups forms of the ring split, the list compaction and the scan-to-scan index build that a one-scan call takes."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
     import replay_synthetic as rp
