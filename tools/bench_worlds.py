@@ -53,19 +53,19 @@ def _register_stats(h, pipe, d_guess, sync, reps):
     return t_reg, k_ms, cand, n_feat
 
 
-def _slam_replay(kind, n):
+def _slam_replay(kind, n, beams=16):
     """BASELINE configs[2]'s per-scan step on a drive through that world, in torch-free child processes like tools/bench_stages.py
     (examples/replay_synthetic.py --world): ms per scan synchronous / pipelined, ATE, gate-closed scans."""
     import subprocess
     out = {}
     for mode in ("slam", "slam-pipelined"):
-        cp = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "replay_synthetic.py"), "--scans", str(n), "--mode", mode, "--world", kind],
+        cp = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "replay_synthetic.py"), "--scans", str(n), "--mode", mode, "--world", kind, "--beams", str(beams)],
                             capture_output=True, text=True, timeout=600)
         if cp.returncode != 0:
             raise RuntimeError("SLAM replay child failed: " + cp.stderr[-2000:])
         out[mode] = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
     a, b = out["slam"], out["slam-pipelined"]
-    return {"scans": n, "ms_per_scan_synchronous": a["ms_per_scan_end_to_end"], "ms_per_scan_pipelined": b["ms_per_scan_end_to_end"],
+    return {"scans": n, "beams": beams, "ms_per_scan_synchronous": a["ms_per_scan_end_to_end"], "ms_per_scan_pipelined": b["ms_per_scan_end_to_end"],
             "ate_rmse_m": a["ate_rmse_m"], "same_final_error": a["final_error_m_rad"] == b["final_error_m_rad"],
             "map_points": a["map_points"], "mean_surrounded_map_points": a["mean_surrounded_map_points"],
             "mean_features_after_voxel": a["mean_features_after_voxel"], "mapping_gate_closed_scans": a["mapping_gate_closed_scans"],
@@ -135,6 +135,8 @@ def measure_worlds(device=0, checker=None, scans=256, reps=5, spot=3, kinds=("ou
         scans = n_sweeps
         if slam_scans > 0:
             out[kind]["slam_step"] = _slam_replay(kind, slam_scans)
+            if kind == "outdoor":                       # the KITTI-scale sensor (64 x 1 900 returns, ~100 k-point less-flat lists) where it belongs
+                out[kind]["slam_step_64_beams"] = _slam_replay(kind, max(20, slam_scans // 2), beams=64)
     return out
 
 

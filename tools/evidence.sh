@@ -21,4 +21,9 @@ for m in "" "--imu" "--reference-quirks" "--imu --reference-quirks"; do
 done > $O/replay300.jsonl
 MSFL_SLAM_HOST_PROFILE=1 timeout 200 python examples/replay_synthetic.py --scans 300 --mode slam-pipelined > /dev/null 2> $O/slam_host_profile.txt
 timeout 600 bash tools/slam_trace.sh 140 > $O/slam_trace.txt 2>&1; cp $R/gpurun_out/tl/*.md $O/ 2>/dev/null
+# round 5b: the step with the 64-beam sensor and in the other worlds: per-stream timelines + 60-scan replays of this build
+for c in "room 40 64" "outdoor 40 64" "corridor 80 16" "outdoor 80 16"; do
+  set -- $c; timeout 300 bash tools/slam_trace_world.sh $c > /dev/null 2>&1; cp $R/gpurun_out/tl_$1_$3/slam-pipelined.md $O/slam_timeline_$1_$3.md 2>/dev/null
+done
+timeout 900 bash tools/slam_ab.sh "-" "room:16 room:64 corridor:16 outdoor:16 outdoor:64" > $O/slam_replays.txt 2>&1
 ls -la $O
