@@ -69,8 +69,11 @@ def _slam_replay(kind, n, beams=16):
             "ate_rmse_m": a["ate_rmse_m"], "same_final_error": a["final_error_m_rad"] == b["final_error_m_rad"],
             "map_points": a["map_points"], "mean_surrounded_map_points": a["mean_surrounded_map_points"],
             "mean_features_after_voxel": a["mean_features_after_voxel"], "mapping_gate_closed_scans": a["mapping_gate_closed_scans"],
-            "note": "parity of this replay against the oracle-driven loop: tests/test_gpu_replay.py::test_device_resident_slam_step_in_the_other_worlds; "
-                    "the corridor's ATE is LOAM's own failure along the unobservable axis (the CPU loop's too)"}
+            "note": ("64 x 1 900 returns per sweep (the sensor of BASELINE configs[3]); parity of the 64-beam step against the oracle-driven loop: "
+                     "tests/test_dataset_io.py::test_kitti_layout_replays_through_the_device_resident_slam_step[64]; a short replay: the first scans' allocations weigh in")
+                    if beams == 64 else
+                    ("parity of this replay against the oracle-driven loop: tests/test_gpu_replay.py::test_device_resident_slam_step_in_the_other_worlds; "
+                     "the corridor's ATE is LOAM's own failure along the unobservable axis (the CPU loop's too)")}
 
 
 def measure_worlds(device=0, checker=None, scans=256, reps=5, spot=3, kinds=("outdoor", "corridor"), copies=4, slam_scans=60):
