@@ -1247,6 +1247,12 @@ constexpr int kVoxSmallPoints = 4096;
 // length, the chunk table has two entries per thread.  65 536 run slots (run ids stay 16-bit); more runs, wider coordinates or more
 // points keep flag 4 and the batch goes to the device-wide form as before.  Launched persistently (voxel_cloud_big_kernel: a fixed
 // number of workgroups walk the list of refused clouds), so the scratch is per workgroup, not per cloud.
+#ifdef MSFL_GRID_PROF
+__device__ unsigned long long g_vox_prof[64 * 8];     // profile build: phase clocks (10 ns ticks) of the last launches, per (form, cloud % 8)
+#define VOX_TICK(k) do { __syncthreads(); if (threadIdx.x == 0) vq[k] = wall_clock64(); } while (0)
+#else
+#define VOX_TICK(k) do { } while (0)
+#endif
 template <int kVoxWaves, int kVoxRunsPerWave, bool kGlobal, bool kBig>
 __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const int b, float4* __restrict__ staging, float4* __restrict__ run_sums,
                                                  int* __restrict__ m_out, int* __restrict__ flags, int only_escalated,
@@ -1287,6 +1293,10 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
   for (int c = tid; c < kMaxChunks; c += kThreads) s_ccnt[c] = 0;
   __syncthreads();
   if (n > kMaxPoints) { if (tid == 0) { flags[b] = kSmall ? 5 : 4; m_out[b] = 0; } return; }
+#ifdef MSFL_GRID_PROF
+  unsigned long long vq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  VOX_TICK(0);
   // ---- phase 1 ----
   const int seg = ((n + kVoxWaves - 1) / kVoxWaves + 63) & ~63;       // points per wavefront, whole chunks
   const int k0 = wave * seg, k1 = min(k0 + seg, n);
@@ -1380,6 +1390,7 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
   }
   if (my_flag) atomicMax(&s_flag, my_flag);
   __syncthreads();
+  VOX_TICK(1);
   // ---- phase 2 ----
   int flag = s_flag;
   if (s_alloc > kVoxMaxRuns) flag = max(flag, kSmall ? 5 : 4);            // more runs than the pool holds
@@ -1433,6 +1444,7 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
   int nbits = 1;
   while ((1ll << nbits) < cells) nbits++;
   __syncthreads();
+  VOX_TICK(2);
   // ---- phase 3: stable LSD radix over the voxel index ----
   const int segE = ((E + kVoxWaves - 1) / kVoxWaves + 63) & ~63;
   const int e0 = min(wave * segE, E), e1 = min(e0 + segE, E);
@@ -1484,6 +1496,7 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
     cur ^= 1;
     __syncthreads();
   }
+  VOX_TICK(3);
   // ---- phase 4: voxel heads (positions in the sorted order) into the other order buffer ----
   unsigned short* heads_at = s_ord(cur ^ 1);
   if (tid == 0) s_total = 0;
@@ -1503,6 +1516,7 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
     __syncthreads();
   }
   const int m = s_total;
+  VOX_TICK(4);
   // ---- phase 5: one thread per voxel ----
   float4* out = staging + v.off[b];
   // Every voxel starts from its first run's sum (phase 1); only later runs (7 % of the voxels of a less-flat list have
@@ -1511,7 +1525,10 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
   // single thread would chain that many dependent loads while its workgroup, the only one on the CU, waits.  Voxels with
   // more than kBigVoxel points after their first run are therefore collected (s_hist is free now) and summed by a whole
   // wavefront each: one coalesced load per run, then the same sequential f32 additions on every lane through broadcasts.
-  constexpr int kBigVoxel = 24;
+#ifndef MSFL_VOX_BIG_VOXEL
+#define MSFL_VOX_BIG_VOXEL 24
+#endif
+  constexpr int kBigVoxel = MSFL_VOX_BIG_VOXEL;
   // s_hist is free now: [0, kMultiCap) lists the voxels with more than one run, the rest the big ones among them
   constexpr int kMultiCap = kVoxWaves * 192, kBigCap = kVoxWaves * 64;
   unsigned short* multi_list = &s_hist[0][0];
@@ -1583,6 +1600,7 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
     out[r] = make_float4(sx / c, sy / c, sz / c, st / c);
   }
   __syncthreads();
+  VOX_TICK(5);
   const int n_big = min(s_nbig, kBigCap);
   for (int q = wave; q < n_big; q += kVoxWaves) {
     const int r = big_list[q];
@@ -1611,6 +1629,14 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
     }
     if (lane == 0) { const float c = (float)total; out[r] = make_float4(sx / c, sy / c, sz / c, st / c); }
   }
+  VOX_TICK(6);
+#ifdef MSFL_GRID_PROF
+  if (tid == 0) {
+    unsigned long long* q = g_vox_prof + (size_t)((kVoxWaves == 4 ? 0 : kGlobal ? 16 : 8) + (b & 7)) * 8;
+    for (int k = 0; k < 6; k++) q[k] = vq[k + 1] - vq[k];
+    q[6] = ((unsigned long long)n << 32) | (unsigned)m; q[7] = ((unsigned long long)E << 32) | ((unsigned)n_multi << 16) | (unsigned)n_big;
+  }
+#endif
   if (tid == 0) { flags[b] = 0; m_out[b] = m; }
 }
 
