@@ -120,6 +120,37 @@ def test_refiltering_a_touched_cell_uses_the_centroids_coordinates(gpu, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_per_cell", [3000, 9000, 40000])
+def test_dense_cells_take_every_form_of_the_rebuild(gpu, oracle, n_per_cell):
+    """A 64-beam sweep puts thousands of points into one 3 m cell, a corridor wall hundreds into one 0.4 m voxel.  3 000 points per
+    cell stay in the LDS form of the rebuild (points staged in LDS, run r summed by thread r), 9 000 take the large form (sort in LDS,
+    wavefront sums for long runs), 40 000 its global-scratch sort; one voxel of each cloud holds 1 500 of the points (one long run).
+    Inserted twice (the second insert merges with the stored centroids), plus a sparse insert that touches the same cells: every dump
+    must equal the oracle's bit for bit."""
+    from msf_loam_amd import capi
+    rng = np.random.default_rng(77 + n_per_cell)
+    def cloud(shift):
+        cells = np.array([[0.0, 0.0, 0.0], [6.0, -3.0, 0.0], [-9.0, 3.0, 3.0]])
+        pts = []
+        for c in cells:
+            p = np.zeros((n_per_cell, 4), np.float32)
+            p[:, :3] = c + rng.uniform(-1.45, 1.45, (n_per_cell, 3)) * np.array([1.0, 1.0, 0.3]) + shift
+            p[:1500, :3] = c + np.array([0.21, 0.21, 0.05]) + rng.uniform(0, 0.15, (1500, 3)) + shift      # one voxel, in arrival order at the front
+            p[:, 3] = rng.uniform(0, 0.1, n_per_cell)
+            pts.append(p)
+        allp = np.concatenate(pts)
+        return allp[rng.permutation(len(allp))] if n_per_cell < 40000 else allp     # shuffled: arrival order interleaves the voxels
+    go, gg = oracle.HybridGrid(3.0, 0.4), capi.Grid(gpu, 3.0, 0.4)
+    sparse = np.array([[0.3, 0.2, 0.1, 0.5], [6.2, -3.1, 0.0, 0.5], [-9.0, 3.0, 3.1, 0.5]], np.float32)
+    for scan in (cloud(0.0), cloud(0.013), sparse):
+        assert go.insert_scan(scan) == 0
+        gg.insert_scan(scan)
+        assert gg.size() == go.size()
+        assert np.array_equal(gg.dump(), go.dump())
+    gg.close()
+
+
+@pytest.mark.gpu
 def test_surrounded_cloud_feeds_set_map_on_device(gpu, oracle):
     """insert -> get_surrounded (device) -> msfl_set_map (device) -> match: the mapping loop without
     the map ever leaving the GPU, against the oracle doing the same through host arrays."""
