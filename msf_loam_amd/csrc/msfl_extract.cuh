@@ -1525,12 +1525,16 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
   // single thread would chain that many dependent loads while its workgroup, the only one on the CU, waits.  Voxels with
   // more than kBigVoxel points after their first run are therefore collected (s_hist is free now) and summed by a whole
   // wavefront each: one coalesced load per run, then the same sequential f32 additions on every lane through broadcasts.
+  // Round 5b: that walk spends eight wave-wide instructions per point (~1 us per run with four wavefronts on a SIMD), the
+  // thread's chain ~0.25 us per point with four loads in flight and every other big voxel's thread running next to it: with
+  // the threshold at 24 the 620 big voxels of a 64-beam list took 307 us of the list's 800 on the wavefront path; it now only
+  // takes voxels a thread would need > 100 us for.  (Tried: the later points as one stream across runs, 8 loads in flight: no gain.)
 #ifndef MSFL_VOX_BIG_VOXEL
-#define MSFL_VOX_BIG_VOXEL 24
+#define MSFL_VOX_BIG_VOXEL 512   /* round 5b (24 until then); measured 8 / 24 / 96 / 400 / off: 64-beam lists 4.62 ms per 1 250 at 24, then 4.00 / 3.81 / 3.76; corridor list 277 / 265 / - / 246 / 231 us */
 #endif
   constexpr int kBigVoxel = MSFL_VOX_BIG_VOXEL;
   // s_hist is free now: [0, kMultiCap) lists the voxels with more than one run, the rest the big ones among them
-  constexpr int kMultiCap = kVoxWaves * 192, kBigCap = kVoxWaves * 64;
+  constexpr int kMultiCap = kVoxWaves * 240, kBigCap = kVoxWaves * 16;     // of s_hist's kVoxWaves x 256 entries (192 / 64 while a big voxel began at 24 points)
   unsigned short* multi_list = &s_hist[0][0];
   unsigned short* big_list = multi_list + kMultiCap;
   __shared__ int s_nbig;
