@@ -1340,7 +1340,11 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
       }
       // a run never crosses a chunk: lane 0 always opens one
       const int q0 = __shfl_up(c0, 1), q1 = __shfl_up(c1, 1), q2 = __shfl_up(c2, 1);
-      const bool head = valid && (lane == 0 || c0 != q0 || c1 != q1 || c2 != q2);
+#ifndef MSFL_VOX_RUN_CAP
+#define MSFL_VOX_RUN_CAP 64
+#endif
+      // (a run may be cut short at will: its voxel then has one more run, summed in the same order; MSFL_VOX_RUN_CAP < 64 bounds the lockstep below)
+      const bool head = valid && (lane == 0 || c0 != q0 || c1 != q1 || c2 != q2 || (MSFL_VOX_RUN_CAP < 64 && (lane & (MSFL_VOX_RUN_CAP - 1)) == 0));
       const unsigned long long heads = __ballot(head), live = __ballot(valid);
       int len = 0;                                                       // of the run this lane opens
       int slot = 0;
