@@ -203,6 +203,32 @@ def test_a_poisoned_pipeline_still_hands_out_the_earlier_results(monkeypatch, th
         slam.close()
 
 
+def test_concurrent_sessions_in_one_process_do_not_disturb_each_other():
+    """Several msfl_slam objects driven from their own host threads (ctypes releases the GIL inside the calls) share the process's HIP
+    runtime and nothing else: every session's pose track must equal the single session's bit for bit, pipelined use included
+    (tools/slam_sessions.py measures what such replicas are worth: nothing, profiles/r05b_slam_sessions.md)."""
+    import sys, os, threading
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import replay_synthetic as rp
+    truth, scans = _scans(25)
+    world = synth.World(ground_half=45.0)
+    ref, _, _ = rp.run_slam(world, truth, pipelined=False, scans=scans)
+    K = 4
+    est = [None] * K
+    gate = threading.Barrier(K)
+
+    def work(i):
+        gate.wait()
+        est[i], _, _ = rp.run_slam(world, truth, pipelined=bool(i % 2), scans=scans)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(K)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert all(e is not None and np.array_equal(e, ref) for e in est)
+
+
 def test_batches_beyond_the_2d_launch_limit_are_refused_up_front(gpu):
     """kernels launched 2-D over (tile, scan / pair) cannot take more than 65 535 rows: MSFL_CAPACITY with a message, before
     any staging, instead of an opaque HIP launch error."""
