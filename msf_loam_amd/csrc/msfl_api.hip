@@ -377,7 +377,10 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
                            (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
                            (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
                            (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(), h->prm.map_knn_max_sq_dist, nn, edge_blocks);
-    } else if (!deskew && (h->knn_form == 2 || (h->knn_form == 0 && n_rec <= kKnnRowsMaxRecords)))
+    } else if (!deskew && (h->knn_form == 2 || (h->knn_form == 0 && (n_rec <= kKnnRowsMaxRecords ||
+                                                                       // the SLAM step launches over the list CAPACITIES (device-side counts): a 64-beam scan's ~11-17 k
+                                                                       // queries sit in a ~150 k-slot launch whose surplus workgroups leave at once
+                                                                       (bv.dyn && n_rec <= 8 * kKnnRowsMaxRecords)))))
       hipLaunchKernelGGL(knn5_scan2map_rows_kernel, dim3(div_up(n_rec, kKnnRowsBlock / kKnnRowLanes)), dim3(kKnnRowsBlock), 0, st, bv, d_poses, d_status,
                          (const GridDesc*)h->map_c.gdesc.as<GridDesc>(), h->map_c.sorted.as<float4>(), h->map_c.cell_start.as<int>(),
                          (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
