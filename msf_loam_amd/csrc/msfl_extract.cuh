@@ -1373,15 +1373,21 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
       // step adds +0, which never changes a sum that started that way.
       {
         const float4 p = pp[u];
-        float sx = 0.f + p.x, sy = 0.f + p.y, sz = 0.f + p.z, st = 0.f + p.w;
+        // Round 5b: the conditional additions as two packed fused multiply-adds with a 1.0 / 0.0 multiplier per lane -- fma(v, 1, s) IS
+        // v + s (one rounding of the exact sum) and fma(v, 0, s) is s for every finite v (a cloud with a non-finite point is refused as a
+        // whole, flag 3, whatever its sums hold): 4 shifts + 1 select + 2 v_pk_fma_f32 per step instead of 4 + 4 + 4.
+        typedef float vox_f2 __attribute__((ext_vector_type(2)));
+        vox_f2 sxy = {0.f + p.x, 0.f + p.y}, szt = {0.f + p.z, 0.f + p.w};
         float vx = p.x, vy = p.y, vz = p.z, vt = p.w;
         const int longest = (int)wave_extremum_u32<true>((unsigned)len);
         for (int e = 1; e < longest; e++) {
           vx = dpp_wave_shl1(vx); vy = dpp_wave_shl1(vy); vz = dpp_wave_shl1(vz); vt = dpp_wave_shl1(vt);
-          const bool on = e < len;
-          sx += on ? vx : 0.f; sy += on ? vy : 0.f; sz += on ? vz : 0.f; st += on ? vt : 0.f;
+          const float on = e < len ? 1.0f : 0.0f;
+          const vox_f2 m = {on, on};
+          sxy = __builtin_elementwise_fma((vox_f2){vx, vy}, m, sxy);
+          szt = __builtin_elementwise_fma((vox_f2){vz, vt}, m, szt);
         }
-        if (head && slot < kVoxMaxRuns) run_sums[v.off[b] + slot] = make_float4(sx, sy, sz, st);     // a cloud has no more runs than points
+        if (head && slot < kVoxMaxRuns) run_sums[v.off[b] + slot] = make_float4(sxy.x, sxy.y, szt.x, szt.y);     // a cloud has no more runs than points
       }
     }
   }
