@@ -1334,6 +1334,10 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
         const float f0 = floorf(p.x * v.inv_leaf), f1 = floorf(p.y * v.inv_leaf), f2 = floorf(p.z * v.inv_leaf);
         if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) my_flag = max(my_flag, 3);
         else if (!(fabsf(f0) < (float)(kCoordOff - 1) && fabsf(f1) < (float)(kCoordOff - 1) && fabsf(f2) < (float)(kCoordOff - 1))) my_flag = max(my_flag, 4);
+        // a finite point whose 4th field (intensity / relative time) is NaN or Inf is a point pcl keeps: its voxel's 4th sum goes non-finite, no
+        // other voxel's does.  The lockstep below multiplies idle lanes' values by 0.0 (0 * NaN = NaN would reach other runs of the chunk), so
+        // such a cloud is summed by the device-wide form, which adds point by point like pcl (flag 4 = "does not fit this form")
+        else if (!(fabsf(p.w) < INFINITY)) my_flag = max(my_flag, 4);
         c0 = (int)f0; c1 = (int)f1; c2 = (int)f2;
         mn[0] = min(mn[0], c0); mn[1] = min(mn[1], c1); mn[2] = min(mn[2], c2);
         mx[0] = max(mx[0], c0); mx[1] = max(mx[1], c1); mx[2] = max(mx[2], c2);
@@ -1374,8 +1378,9 @@ __device__ __forceinline__ void voxel_cloud_body(const VoxelBatchView& v, const 
       {
         const float4 p = pp[u];
         // Round 5b: the conditional additions as two packed fused multiply-adds with a 1.0 / 0.0 multiplier per lane -- fma(v, 1, s) IS
-        // v + s (one rounding of the exact sum) and fma(v, 0, s) is s for every finite v (a cloud with a non-finite point is refused as a
-        // whole, flag 3, whatever its sums hold): 4 shifts + 1 select + 2 v_pk_fma_f32 per step instead of 4 + 4 + 4.
+        // v + s (one rounding of the exact sum) and fma(v, 0, s) is s for every finite v (a cloud with a non-finite coordinate is refused as a
+        // whole, flag 3, one with a non-finite 4th field leaves for the device-wide form, flag 4, whatever the sums here hold): 4 shifts +
+        // 1 select + 2 v_pk_fma_f32 per step instead of 4 + 4 + 4.
         typedef float vox_f2 __attribute__((ext_vector_type(2)));
         vox_f2 sxy = {0.f + p.x, 0.f + p.y}, szt = {0.f + p.z, 0.f + p.w};
         float vx = p.x, vy = p.y, vz = p.z, vt = p.w;

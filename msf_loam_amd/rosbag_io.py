@@ -27,10 +27,12 @@ _MAGIC = b"#ROSBAG V2.0\n"
 _LZ4_MAGIC = 0x184D2204
 
 
-def lz4_block_decompress(src, max_out=None):
+def lz4_block_decompress(src, max_out=None, prefix=b""):
     """One LZ4 block -> bytes.  Sequences of (token, [literal length extension], literals, offset u16, [match length extension]); the
-    last sequence ends after its literals.  A match may overlap its own output (offset < length: a run)."""
-    out = bytearray()
+    last sequence ends after its literals.  A match may overlap its own output (offset < length: a run).  `prefix`: the output that
+    precedes this block in a block-LINKED frame (its last 64 KB are all a match can reach); the returned bytes are the block's own."""
+    out = bytearray(prefix)
+    base = len(out)
     i, n = 0, len(src)
     while i < n:
         token = src[i]; i += 1
@@ -52,7 +54,7 @@ def lz4_block_decompress(src, max_out=None):
             raise ValueError("lz4 block: truncated match offset")
         off = src[i] | (src[i + 1] << 8); i += 2
         if off == 0 or off > len(out):
-            raise ValueError("lz4 block: match offset %d outside the %d bytes decoded so far" % (off, len(out)))
+            raise ValueError("lz4 block: match offset %d outside the %d bytes decoded so far (%d of them history of earlier blocks)" % (off, len(out), base))
         ml = token & 15
         if ml == 15:
             while True:
@@ -69,9 +71,9 @@ def lz4_block_decompress(src, max_out=None):
         else:                                                # overlapping copy: the pattern of `off` bytes repeats
             pat = bytes(out[start:])
             out += (pat * (ml // off + 1))[:ml]
-        if max_out is not None and len(out) > max_out:
+        if max_out is not None and len(out) - base > max_out:
             raise ValueError("lz4 block: output exceeds the declared size")
-    return bytes(out)
+    return bytes(out[base:])
 
 
 def lz4_frame_decompress(buf, expect_size=None):
@@ -81,13 +83,13 @@ def lz4_frame_decompress(buf, expect_size=None):
     flg, bd = buf[4], buf[5]
     if (flg >> 6) != 1:
         raise ValueError("lz4 frame: unsupported version %d" % (flg >> 6))
-    block_checksum, has_size, content_checksum, has_dict = (flg >> 4) & 1, (flg >> 3) & 1, (flg >> 2) & 1, flg & 1
+    independent, block_checksum, has_size, content_checksum, has_dict = (flg >> 5) & 1, (flg >> 4) & 1, (flg >> 3) & 1, (flg >> 2) & 1, flg & 1
+    if has_dict:
+        raise ValueError("lz4 frame: frames that need an external dictionary are not supported")
     i = 6
     content_size = None
     if has_size:
         (content_size,) = struct.unpack_from("<Q", buf, i); i += 8
-    if has_dict:
-        i += 4
     i += 1                                                    # header checksum byte ((xxh32(descriptor) >> 8) & 0xff): checked when xxhash is there
     try:
         import xxhash
@@ -98,7 +100,9 @@ def lz4_frame_decompress(buf, expect_size=None):
     block_max = {4: 64 << 10, 5: 256 << 10, 6: 1 << 20, 7: 4 << 20}.get((bd >> 4) & 7)
     if block_max is None:
         raise ValueError("lz4 frame: bad block size id %d" % ((bd >> 4) & 7))
-    out = []
+    # Block-LINKED frames (FLG bit 5 clear: liblz4's LZ4F default, what the lz4 command line tool writes) let a match reach into the
+    # up to 64 KB of output before its block; roslz4 writes independent blocks.  Both are decoded.
+    res = bytearray()
     while True:
         if i + 4 > len(buf):
             raise ValueError("lz4 frame: truncated (no end mark)")
@@ -110,9 +114,18 @@ def lz4_frame_decompress(buf, expect_size=None):
             raise ValueError("lz4 frame: block runs past the end of the chunk")
         data = buf[i:i + sz]; i += sz
         if block_checksum:
+            if i + 4 > len(buf):
+                raise ValueError("lz4 frame: truncated block checksum")
+            if xxhash is not None and struct.unpack_from("<I", buf, i)[0] != xxhash.xxh32(bytes(data), seed=0).intdigest():
+                raise ValueError("lz4 frame: block checksum mismatch")
             i += 4
-        out.append(bytes(data) if stored else lz4_block_decompress(data, block_max))
-    res = b"".join(out)
+        if stored:
+            if sz > block_max:
+                raise ValueError("lz4 frame: stored block larger than the frame's block size")
+            res += data
+        else:
+            res += lz4_block_decompress(data, block_max, b"" if independent else bytes(res[-65536:]))
+    res = bytes(res)
     if content_checksum:
         if i + 4 > len(buf):
             raise ValueError("lz4 frame: truncated content checksum")
@@ -125,12 +138,17 @@ def lz4_frame_decompress(buf, expect_size=None):
     return res
 
 
-def _lz4_block_compress(data):
-    """Greedy LZ4 block encoder for the writer / fixtures (4-byte hash table, first match wins): valid, not tuned."""
+def _lz4_block_compress(data, prefix=b""):
+    """Greedy LZ4 block encoder for the writer / fixtures (4-byte hash table, first match wins): valid, not tuned.  `prefix`: history a
+    block of a LINKED frame may refer to (the <= 64 KB of input before it)."""
+    base = len(prefix)
+    data = bytes(prefix) + bytes(data)
     n = len(data)
     out = bytearray()
     table = {}
-    anchor = i = 0
+    for j in range(0, max(base - 3, 0)):
+        table[data[j:j + 4]] = j
+    anchor = i = base
     def emit(lit_end, ml=None, off=0):
         lit = lit_end - anchor
         token = (min(lit, 15) << 4) | (0 if ml is None else min(ml - 4, 15))
@@ -165,23 +183,28 @@ def _lz4_block_compress(data):
     return bytes(out)
 
 
-def lz4_frame_compress(data, block=64 << 10):
-    """An LZ4 frame like roslz4 writes (version 1, independent blocks, content checksum when xxhash is importable)."""
+def lz4_frame_compress(data, block=64 << 10, linked=False, block_checksums=False):
+    """An LZ4 frame like roslz4 writes (version 1, independent blocks, content checksum when xxhash is importable).  `linked`: blocks
+    that refer to the 64 KB before them (liblz4's LZ4F default; for the reader's fixtures); `block_checksums`: xxh32 after each block."""
     try:
         import xxhash
     except ImportError:
         xxhash = None
-    flg = (1 << 6) | (1 << 5) | ((1 << 2) if xxhash else 0)
+    block_checksums = bool(block_checksums and xxhash)
+    flg = (1 << 6) | (0 if linked else (1 << 5)) | ((1 << 4) if block_checksums else 0) | ((1 << 2) if xxhash else 0)
     desc = bytes([flg, 4 << 4])
     hc = (xxhash.xxh32(desc, seed=0).intdigest() >> 8) & 0xff if xxhash else 0
     out = [struct.pack("<I", _LZ4_MAGIC), desc, bytes([hc])]
     for o in range(0, len(data), block):
         raw = data[o:o + block]
-        c = _lz4_block_compress(raw)
+        c = _lz4_block_compress(raw, data[max(o - 65536, 0):o] if linked else b"")
         if len(c) < len(raw):
             out += [struct.pack("<I", len(c)), c]
         else:
+            c = raw
             out += [struct.pack("<I", len(raw) | 0x80000000), raw]
+        if block_checksums:
+            out.append(struct.pack("<I", xxhash.xxh32(bytes(c), seed=0).intdigest()))
     out.append(struct.pack("<I", 0))
     if xxhash:
         out.append(struct.pack("<I", xxhash.xxh32(data, seed=0).intdigest()))

@@ -527,3 +527,41 @@ def test_voxel_lists_beyond_the_lds_forms_and_pooled_run_slots(oracle, monkeypat
     finally:
         for h in hs.values():
             h.close()
+
+
+def test_non_finite_fourth_field_stays_in_its_own_voxel_in_every_form(oracle, monkeypatch):
+    """ADVICE r05.  A point with finite coordinates and a NaN / Inf 4th field (intensity / relative time) is a point pcl::VoxelGrid KEEPS:
+    its voxel's 4th sum goes non-finite and no other voxel's does.  The one-workgroup forms sum a chunk's runs in lockstep with a
+    1.0 / 0.0 multiplier per lane (0 * NaN = NaN would leak into the other runs of the chunk), so they hand such a cloud to the
+    device-wide form, which adds point by point.  Every entry point and every form equals the oracle (NaN compared as NaN), the
+    other clouds of the batch are untouched, and the finite columns are bit-identical."""
+    from msf_loam_amd import capi
+    rng = np.random.default_rng(77)
+    small = _sweep_cloud(rng, 6000)
+    big = _sweep_cloud(rng, 100_000)
+    hs = {}
+    hs["default"] = capi.Handle(0)
+    monkeypatch.setenv("MSFL_VOXEL_NO_BIG", "1"); hs["no_big"] = capi.Handle(0); monkeypatch.delenv("MSFL_VOXEL_NO_BIG")
+    monkeypatch.setenv("MSFL_VOXEL_GLOBAL", "1"); hs["global"] = capi.Handle(0); monkeypatch.delenv("MSFL_VOXEL_GLOBAL")
+    try:
+        for bad in (np.nan, np.inf, -np.inf):
+            for base in (small, big):
+                q = base.copy()
+                hit = rng.choice(len(q), 23, replace=False)
+                q[hit, 3] = bad
+                if bad == np.inf: q[hit[0], 3] = -np.inf                      # +Inf and -Inf meeting in one sum is fine too
+                ref = oracle.voxel_grid(q, 0.4)
+                n_bad = int((~np.isfinite(ref[:, 3])).sum())
+                assert 1 <= n_bad <= 23 and np.isfinite(ref[:, :3]).all()
+                for name, h in hs.items():
+                    out = h.voxel_downsample(q, 0.4)
+                    assert np.array_equal(out, ref, equal_nan=True), (name, bad, len(q))
+                    assert np.array_equal(out[:, :3], ref[:, :3])
+                    clouds = [small, q, small[:1500]]
+                    off = np.cumsum([0] + [len(c) for c in clouds]).astype(np.int32)
+                    o, oo = h.voxel_downsample_batch(np.concatenate(clouds), off, 0.4)
+                    for b, c in enumerate(clouds):
+                        assert np.array_equal(o[oo[b]:oo[b + 1]], oracle.voxel_grid(c, 0.4), equal_nan=True), (name, bad, b)
+    finally:
+        for h in hs.values():
+            h.close()

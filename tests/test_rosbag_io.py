@@ -127,6 +127,45 @@ def test_lz4_block_and_frame_known_answers():
         assert rb.lz4_frame_decompress(rb.lz4_frame_compress(data), len(data)) == data
 
 
+def test_lz4_block_linked_frames_and_block_checksums():
+    """ADVICE r05.  liblz4's LZ4F default (and the lz4 command line tool) writes block-LINKED frames: FLG bit 5 clear, a match may reach
+    into the up to 64 KB of output before its block.  Hand-assembled known answer, the refusal when the same blocks are labelled
+    independent, per-block checksums verified, and the module's encoder / decoder pair on inputs whose repetitions span blocks."""
+    try:
+        import xxhash
+    except ImportError:
+        xxhash = None
+    def header(flg, bd=0x40):
+        hc = (xxhash.xxh32(bytes([flg, bd]), seed=0).intdigest() >> 8) & 0xff if xxhash else 0
+        return struct.pack("<I", 0x184D2204) + bytes([flg, bd, hc])
+    b1 = bytes([0x80]) + b"abcdefgh"                                             # eight literals, end of block
+    b2 = bytes([0x04, 8, 0]) + bytes([0x50]) + b"xyz12"                          # no literals + match(offset 8, length 8) INTO block 1, then the last literals
+    body = struct.pack("<I", len(b1)) + b1 + struct.pack("<I", len(b2)) + b2 + struct.pack("<I", 0)
+    assert rb.lz4_frame_decompress(header(0x40) + body) == b"abcdefgh" * 2 + b"xyz12"
+    with pytest.raises(ValueError, match="history"):
+        rb.lz4_frame_decompress(header(0x60) + body)                             # the same blocks labelled independent: no history to reach into
+    # a match that starts in the history and runs on into its own output (offset 8, length 20 over an 8-byte history)
+    b3 = bytes([0x0F, 8, 0, 1]) + bytes([0x50]) + b"xyz12"
+    assert rb.lz4_frame_decompress(header(0x40) + struct.pack("<I", len(b1)) + b1 + struct.pack("<I", len(b3)) + b3 + struct.pack("<I", 0)) == b"abcdefgh" + (b"abcdefgh" * 3)[:20] + b"xyz12"
+    with pytest.raises(ValueError, match="dictionary"):
+        rb.lz4_frame_decompress(header(0x41) + struct.pack("<I", 0) + body)
+    if xxhash:
+        def ck(b): return struct.pack("<I", xxhash.xxh32(b, seed=0).intdigest())
+        good = header(0x50) + struct.pack("<I", len(b1)) + b1 + ck(b1) + struct.pack("<I", len(b2)) + b2 + ck(b2) + struct.pack("<I", 0)
+        assert rb.lz4_frame_decompress(good) == b"abcdefgh" * 2 + b"xyz12"
+        bad = bytearray(good); bad[7 + 4 + len(b1)] ^= 1
+        with pytest.raises(ValueError, match="block checksum"):
+            rb.lz4_frame_decompress(bytes(bad))
+    rng = np.random.default_rng(2)
+    for data in (b"abcdefgh" * 20000, bytes(rng.integers(0, 4, 200000, dtype=np.uint8)), bytes(rng.integers(0, 256, 70000, dtype=np.uint8)) * 2, b"q" * 65537):
+        for kw in (dict(linked=True), dict(linked=True, block_checksums=True), dict(block_checksums=True), dict(linked=True, block=4 << 10)):
+            f = rb.lz4_frame_compress(data, **kw)
+            assert rb.lz4_frame_decompress(f, len(data)) == data
+    # the linked encoder really uses the history (otherwise the fixture proves nothing): a block that repeats the previous one shrinks to a few bytes
+    rep = bytes(rng.integers(0, 256, 4096, dtype=np.uint8)) * 4
+    assert len(rb.lz4_frame_compress(rep, block=4096, linked=True)) < 4096 + 600 < len(rb.lz4_frame_compress(rep, block=4096))
+
+
 def test_lz4_bag_round_trip_and_time_merge(tmp_path):
     rng = np.random.default_rng(3)
     clouds = [(rng.normal(size=(300 + 11 * k, 4)).astype(np.float32), rng.integers(0, 16, 300 + 11 * k).astype(np.uint16)) for k in range(7)]
