@@ -152,7 +152,9 @@ struct msfl_handle_s {
 
   // scratch
   DevBuf in_corner, in_surf, in_off, poses, status, info, records, pprime, nn;
-  DevBuf idx_cell_of, idx_count, idx_bbox, idx_cub, idx_stage;
+  std::vector<int> in_off_host; const void* in_off_host_ptr = nullptr;   // what in_off holds on the device (upload_in_off)
+  DevBuf idx_cell_of, idx_count, idx_scanned, idx_bbox, idx_cub, idx_stage;
+  bool index_single = false;   // MSFL_INDEX_SINGLE=1: msfl_set_map builds its two indexes one after the other (the rounds 1-5 form; A/B and parity of the pair build)
   DevBuf knn_count;            // one u64: candidates evaluated by the counting 5-NN instantiation (timing mode 3)
   size_t idx_count_zero = 0;   // leading ints of idx_count known to be zero on the stream
   DevBuf dk[5];
@@ -221,6 +223,18 @@ void collect_timing(msfl_handle* h) {
     h->free_events.push_back(s.a); h->free_events.push_back(s.b);
   }
   h->spans.clear();
+}
+
+// The offset table of a batch on the device (h->in_off).  Registering the same batch layout again (a replayed or re-registered batch: the
+// bench step, a retry after msfl_set_map) skips the copy: it is one more dependent operation on the stream in front of the first kernel.
+msfl_status upload_in_off(msfl_handle* h, const int* data, size_t count, hipStream_t st) {
+  HIPCHK(h, h->in_off.reserve(count * sizeof(int)));
+  if (h->in_off_host.size() == count && h->in_off_host_ptr == h->in_off.p && std::memcmp(h->in_off_host.data(), data, count * sizeof(int)) == 0)
+    return MSFL_OK;
+  h->in_off_host.clear();                       // (stays empty if the upload fails)
+  HIPCHK(h, h->pin.upload(h->in_off.p, data, count * sizeof(int), st));
+  h->in_off_host.assign(data, data + count); h->in_off_host_ptr = h->in_off.p;
+  return MSFL_OK;
 }
 
 SolverParams solver_params(const msfl_params& p, int min_corr) {
@@ -315,6 +329,74 @@ msfl_status build_index(msfl_handle* h, const float4* pts, int n, MapIndex& mi, 
     HIPCHK(h, hipEventRecord(mi.want_ev, st));
     mi.want_pending = true;
   }
+  return MSFL_OK;
+}
+
+// Both maps of msfl_set_map through one chain of five launches (msfl_kernels.cuh: GridPairJob).  Same results as two build_index calls;
+// used when both clouds are non-empty and their sizes are host-side numbers (the per-scan SLAM step builds its maps on streams of their own).
+// The wanted table size comes back through a pinned host word the scatter launch writes (no copy, no event): it is a hint for the NEXT
+// build's table span, so whichever value the host happens to see -- the previous build's or this one's -- is fine.
+msfl_status build_index_pair(msfl_handle* h, const float4* pts_c, int n_c, const float4* pts_s, int n_s) {
+  ScopedTimer timer(h, T_INDEX);
+  if ((long long)n_c >= (1 << 28) || (long long)n_s >= (1 << 28))
+    return fail(h, MSFL_BAD_ARG, "map cloud of 2^28 points or more (the index addresses 16-byte points by 32-bit byte offsets)");
+  hipStream_t st = h->stream;
+  MapIndex* mi[2] = {&h->map_c, &h->map_s};
+  const float4* pts[2] = {pts_c, pts_s};
+  const int n[2] = {n_c, n_s};
+  GridPairJob j;
+  for (int m = 0; m < 2; m++) {
+    MapIndex& x = *mi[m];
+    x.n_input = n[m];
+    if (!x.want_host) {
+      HIPCHK(h, hipHostMalloc((void**)&x.want_host, sizeof(int), hipHostMallocDefault));
+      HIPCHK(h, hipEventCreateWithFlags(&x.want_ev, hipEventDisableTiming));
+      *x.want_host = 0;
+    }
+    if (x.want_pending) { HIPCHK(h, hipEventSynchronize(x.want_ev)); x.want_pending = false; }   // a read-back copy of an earlier single build
+    const int seen = *(volatile int*)x.want_host;
+    if (seen > 0) {
+      const long long w = (long long)seen + seen / 4 + 1024;
+      x.span = (int)std::min<long long>(std::max<long long>(w, 65536), h->grid_cap_cells);
+    }
+    if (x.span <= 0) x.span = std::min(1 << 20, h->grid_cap_cells);
+    x.cap_cells = x.span;
+    HIPCHK(h, x.gdesc.reserve(sizeof(GridDesc)));
+    HIPCHK(h, x.cell_start.reserve(((size_t)x.span + 1) * sizeof(int)));
+    HIPCHK(h, x.sorted.reserve((size_t)n[m] * sizeof(float4)));
+    HIPCHK(h, x.pos_of.reserve((size_t)n[m] * sizeof(int)));
+    if (!x.bbox.p) {                       // armed once; every build re-arms it after the last read
+      HIPCHK(h, x.bbox.reserve(6 * sizeof(int)));
+      const int init[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
+      HIPCHK(h, h->pin.upload(x.bbox.p, init, sizeof(init), st));
+    }
+    j.pts[m] = pts[m]; j.n[m] = n[m]; j.bbox[m] = x.bbox.as<int>(); j.gdesc[m] = x.gdesc.as<GridDesc>(); j.cap[m] = x.span;
+    j.cell_start[m] = x.cell_start.as<int>(); j.sorted[m] = x.sorted.as<float4>(); j.pos_of[m] = x.pos_of.as<int>();
+    j.want_host[m] = x.want_host;
+  }
+  const size_t span = (size_t)j.cap[0] + 1 + (size_t)j.cap[1] + 1;
+  HIPCHK(h, h->idx_cell_of.reserve(((size_t)n_c + (size_t)n_s) * sizeof(int)));
+  const void* count_before = h->idx_count.p;
+  HIPCHK(h, h->idx_count.reserve(span * sizeof(int)));
+  if (h->idx_count.p != count_before) h->idx_count_zero = 0;
+  HIPCHK(h, h->idx_scanned.reserve(span * sizeof(int)));
+  j.cell_of = h->idx_cell_of.as<int>(); j.count = h->idx_count.as<int>(); j.scanned = h->idx_scanned.as<int>();
+  j.blocks0 = div_up(n_c, 256); j.bbox_blocks0 = std::min(div_up(n_c, 1024), 256);
+  j.radius = std::sqrt((double)h->prm.map_knn_max_sq_dist);
+  const int bbox_blocks1 = std::min(div_up(n_s, 1024), 256), blocks1 = div_up(n_s, 256);
+  hipLaunchKernelGGL(grid_bbox_pair_kernel, dim3(j.bbox_blocks0 + bbox_blocks1), dim3(256), 0, st, j);
+  // the scatter launch counts every cell back down to zero: the table only needs clearing when it is new or larger than what has been cleared
+  const size_t zeroed = h->idx_count_zero;
+  h->idx_count_zero = 0;
+  if (span > zeroed) HIPCHK(h, hipMemsetAsync(h->idx_count.p, 0, span * sizeof(int), st));
+  hipLaunchKernelGGL(grid_count_pair_kernel, dim3(j.blocks0 + blocks1), dim3(256), 0, st, j);
+  size_t tmp_bytes = 0;
+  HIPCHK(h, rocprim::exclusive_scan(nullptr, tmp_bytes, j.count, j.scanned, 0, span, rocprim::plus<int>(), st));
+  HIPCHK(h, h->idx_cub.reserve(tmp_bytes));
+  HIPCHK(h, rocprim::exclusive_scan(h->idx_cub.p, tmp_bytes, j.count, j.scanned, 0, span, rocprim::plus<int>(), st));
+  hipLaunchKernelGGL(grid_scatter_pair_kernel, dim3(j.blocks0 + blocks1), dim3(256), 0, st, j);
+  HIPCHK(h, hipGetLastError());
+  h->idx_count_zero = std::max(zeroed, span);
   return MSFL_OK;
 }
 
@@ -454,8 +536,7 @@ msfl_status match_scan2map_device(msfl_handle* h, int B, const float4* d_corner,
       return fail(h, MSFL_BAD_ARG, "offset arrays must be non-decreasing");
   }
   const int n_rec = offs[2 * (B + 1) + B];
-  HIPCHK(h, h->in_off.reserve(offs.size() * sizeof(int)));
-  HIPCHK(h, h->pin.upload(h->in_off.p, offs.data(), offs.size() * sizeof(int), st));
+  { const msfl_status us = upload_in_off(h, offs.data(), offs.size(), st); if (us) return us; }
   HIPCHK(h, h->records.reserve(std::max<size_t>(1, (size_t)n_rec) * 6 * sizeof(double)));
   HIPCHK(h, h->nn.reserve(std::max<size_t>(1, (size_t)n_rec) * 5 * sizeof(int)));
   BatchView bv;
@@ -576,6 +657,7 @@ msfl_status msfl_create(const msfl_params* params, int device, msfl_handle** out
   if (const char* e = std::getenv("MSFL_H2D_CHUNK_SCANS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_chunk_scans = c; }
   if (const char* e = std::getenv("MSFL_H2D_SUB_CHUNKS")) { const int c = std::atoi(e); if (c >= 1) h->h2d_sub_chunks = c; }
   if (const char* e = std::getenv("MSFL_ODOM_BRUTE")) h->odom_force_brute = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MSFL_INDEX_SINGLE")) h->index_single = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSFL_KNN_SEED")) h->knn_seed = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSFL_KNN_FORM")) h->knn_form = !std::strcmp(e, "lane") ? 1 : !std::strcmp(e, "rows") ? 2 : 0;
   if (const char* e = std::getenv("MSFL_ODOM_WAVE_MAX_TARGETS")) h->odom_wave_max_targets = std::atoll(e);
@@ -614,7 +696,7 @@ void msfl_destroy(msfl_handle* h) {
   DevBuf* bufs[] = {&h->map_c.sorted, &h->map_c.cell_start, &h->map_s.sorted, &h->map_s.cell_start, &h->map_c.pos_of, &h->map_s.pos_of,
                     &h->map_c.gdesc, &h->map_s.gdesc, &h->map_c.bbox, &h->map_s.bbox, &h->in_corner,
                     &h->in_surf, &h->in_off, &h->poses, &h->status, &h->info, &h->records, &h->pprime, &h->nn,
-                    &h->idx_cell_of, &h->idx_count, &h->idx_bbox, &h->idx_cub, &h->idx_stage, &h->knn_count};
+                    &h->idx_cell_of, &h->idx_count, &h->idx_scanned, &h->idx_bbox, &h->idx_cub, &h->idx_stage, &h->knn_count};
   for (auto* b : bufs) b->release();
   for (auto& b : h->dk) b.release();
   for (auto& b : h->ex) b.release();
@@ -716,8 +798,12 @@ msfl_status msfl_set_map(msfl_handle* h, const msfl_point* corner, int n_corner,
     if (n_surf) HIPCHK(h, hipMemcpyAsync(stage + n_corner, surf, (size_t)n_surf * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     dc = stage; ds = stage + n_corner;
   }
-  s = build_index(h, dc, n_corner, h->map_c); if (s) return s;
-  s = build_index(h, ds, n_surf, h->map_s); if (s) return s;
+  if (n_corner > 0 && n_surf > 0 && !h->index_single) {
+    s = build_index_pair(h, dc, n_corner, ds, n_surf); if (s) return s;
+  } else {
+    s = build_index(h, dc, n_corner, h->map_c); if (s) return s;
+    s = build_index(h, ds, n_surf, h->map_s); if (s) return s;
+  }
   // host arrays were staged with asynchronous copies from pageable memory: they must have been read
   // before the caller may touch them again.  Device-resident maps stay fully asynchronous.
   if (mem == MSFL_MEM_HOST) HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -885,7 +971,7 @@ static msfl_status stage_single(msfl_handle* h, const msfl_point* corner, int n_
   HIPCHK(h, h->in_surf.reserve(std::max<size_t>(1, (size_t)n_surf) * sizeof(float4)));
   HIPCHK(h, h->poses.reserve(7 * sizeof(double)));
   HIPCHK(h, h->status.reserve(sizeof(int)));
-  HIPCHK(h, h->in_off.reserve(6 * sizeof(int)));
+
   HIPCHK(h, h->records.reserve(std::max<size_t>(1, (size_t)(n_corner + n_surf)) * 6 * sizeof(double)));
   HIPCHK(h, h->nn.reserve(std::max<size_t>(1, (size_t)(n_corner + n_surf)) * 5 * sizeof(int)));
   if (n_corner) HIPCHK(h, hipMemcpyAsync(h->in_corner.p, corner, (size_t)n_corner * sizeof(float4), hipMemcpyHostToDevice, st));
@@ -893,7 +979,7 @@ static msfl_status stage_single(msfl_handle* h, const msfl_point* corner, int n_
   HIPCHK(h, hipMemcpyAsync(h->poses.p, pose, 7 * sizeof(double), hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemsetAsync(h->status.p, 0, sizeof(int), st));
   const int offs[6] = {0, n_corner, 0, n_surf, 0, n_corner + n_surf};
-  HIPCHK(h, h->pin.upload(h->in_off.p, offs, sizeof(offs), st));
+  { const msfl_status us = upload_in_off(h, offs, 6, st); if (us) return us; }
   bv.corner = h->in_corner.as<float4>(); bv.corner_off = h->in_off.as<int>();
   bv.surf = h->in_surf.as<float4>(); bv.surf_off = h->in_off.as<int>() + 2;
   bv.rec_off = h->in_off.as<int>() + 4;

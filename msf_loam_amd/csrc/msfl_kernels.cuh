@@ -60,9 +60,8 @@ __host__ __device__ __forceinline__ float ordered_to_float(int i) {
 // bbox[0..2] = min (ordered ints), bbox[3..5] = max; pre-initialised to INT_MAX / INT_MIN
 // n_dev (optional): the number of valid points lives on the device (a surrounded cloud that never visits the host);
 // `n` is then the launch's upper bound
-__global__ void __launch_bounds__(256) grid_bbox_kernel(const float4* __restrict__ pts, int n, int* __restrict__ bbox, const int* __restrict__ n_dev = nullptr) {
+__device__ __forceinline__ void grid_bbox_body(const float4* __restrict__ pts, int n, int* __restrict__ bbox, int block, int n_blocks) {
   __shared__ float s_mn[4][3], s_mx[4][3];
-  if (n_dev) n = min(n, max(*n_dev, 0));
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   auto take = [&](float4 p) {
     if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
@@ -70,8 +69,8 @@ __global__ void __launch_bounds__(256) grid_bbox_kernel(const float4* __restrict
       mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
     }
   };
-  const int stride = gridDim.x * blockDim.x;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int stride = n_blocks * blockDim.x;
+  int i = block * blockDim.x + threadIdx.x;
   for (; i + 3 * stride < n; i += 4 * stride) {       // four independent loads in flight per lane
     const float4 p0 = pts[i], p1 = pts[i + stride], p2 = pts[i + 2 * stride], p3 = pts[i + 3 * stride];
     take(p0); take(p1); take(p2); take(p3);
@@ -101,6 +100,10 @@ __global__ void __launch_bounds__(256) grid_bbox_kernel(const float4* __restrict
     const float v = fmaxf(fmaxf(s_mx[0][a], s_mx[1][a]), fmaxf(s_mx[2][a], s_mx[3][a]));
     if (v != -INFINITY) atomicMax(&bbox[3 + a], float_to_ordered(v));
   }
+}
+__global__ void __launch_bounds__(256) grid_bbox_kernel(const float4* __restrict__ pts, int n, int* __restrict__ bbox, const int* __restrict__ n_dev = nullptr) {
+  if (n_dev) n = min(n, max(*n_dev, 0));
+  grid_bbox_body(pts, n, bbox, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __device__ __forceinline__ int grid_coord(float v, float o, float inv, int dim) {
@@ -166,17 +169,16 @@ __global__ void grid_setup_kernel(int* __restrict__ bbox, double radius, int cap
 
 // Every workgroup derives the (identical) descriptor from the finished bbox itself: one launch less
 // per build than a separate one-thread setup kernel; workgroup 0 publishes it.
-__global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restrict__ pts, int n, const int* __restrict__ bbox,
-                                                          double radius, int cap_cells, GridDesc* __restrict__ gout,
-                                                          int* __restrict__ cell_of, int* __restrict__ count, const int* __restrict__ n_dev = nullptr) {
+__device__ __forceinline__ void grid_count_body(const float4* __restrict__ pts, int n, const int* __restrict__ bbox,
+                                                double radius, int cap_cells, GridDesc* __restrict__ gout,
+                                                int* __restrict__ cell_of, int* __restrict__ count, int block) {
   __shared__ GridDesc s_g;
-  if (n_dev) n = min(n, max(*n_dev, 0));
   if (threadIdx.x == 0) {
     s_g = grid_desc_from_bbox(bbox, radius, cap_cells);
-    if (blockIdx.x == 0) *gout = s_g;
+    if (block == 0) *gout = s_g;
   }
   __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = block * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const GridDesc g = s_g;
   const float4 p = pts[i];
@@ -189,6 +191,12 @@ __global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restric
     atomicAdd(&count[c], 1);
   }
   cell_of[i] = c;
+}
+__global__ void __launch_bounds__(256) grid_count_kernel(const float4* __restrict__ pts, int n, const int* __restrict__ bbox,
+                                                          double radius, int cap_cells, GridDesc* __restrict__ gout,
+                                                          int* __restrict__ cell_of, int* __restrict__ count, const int* __restrict__ n_dev = nullptr) {
+  if (n_dev) n = min(n, max(*n_dev, 0));
+  grid_count_body(pts, n, bbox, radius, cap_cells, gout, cell_of, count, (int)blockIdx.x);
 }
 
 // cursor[] holds the per-cell counts on entry and is consumed — it is all zeros again afterwards, so
@@ -210,6 +218,66 @@ __global__ void __launch_bounds__(256) grid_scatter_kernel(const float4* __restr
   p.w = __int_as_float(i);
   sorted[cell_start[c] + k] = p;
   pos_of[i] = cell_start[c] + k;      // original index -> position (the fit kernel fetches by index)
+}
+
+// ---- both maps of msfl_set_map through ONE chain of launches (round 6) -------------------------------------------------------
+// The corner map (a few thousand points) and the surf map used to be indexed one after the other: ten launches and two 4-byte
+// read-back copies in front of every batch, ~45 us of mostly launch-to-launch latency.  Here every launch serves both clouds
+// (blocks [0, blocks0) the first, the rest the second), the two count tables sit back to back and are prefix-summed by ONE
+// rocPRIM scan, and the scatter launch also writes each map's own cell table from the combined sums (the second map's minus the
+// first map's total) and the grids' wanted size straight into pinned host memory.  Same descriptors, same tables, same sorted
+// copies up to the (arbitrary, never observable) order inside a cell as two single builds.
+struct GridPairJob {
+  const float4* pts[2]; int n[2];
+  int* bbox[2]; GridDesc* gdesc[2]; int cap[2];
+  int* cell_of;              // [n[0] | n[1]]
+  int* count;                // [cap[0] + 1 | cap[1] + 1], zero on entry, zero again on exit
+  int* scanned;              // exclusive prefix sums of `count` over both tables (the scatter launch reads them)
+  int* cell_start[2]; float4* sorted[2]; int* pos_of[2];
+  int* want_host[2];         // pinned host words: cells the bounding box needs at the base cell edge (feedback for the next build)
+  int blocks0;               // workgroups of the per-point launches that serve map 0
+  int bbox_blocks0;          // the same for the bounding-box launch
+  double radius;
+};
+__global__ void __launch_bounds__(256) grid_bbox_pair_kernel(GridPairJob j) {
+  const int m = (int)blockIdx.x < j.bbox_blocks0 ? 0 : 1;
+  const int block = m ? (int)blockIdx.x - j.bbox_blocks0 : (int)blockIdx.x;
+  grid_bbox_body(j.pts[m], j.n[m], j.bbox[m], block, m ? (int)gridDim.x - j.bbox_blocks0 : j.bbox_blocks0);
+}
+__global__ void __launch_bounds__(256) grid_count_pair_kernel(GridPairJob j) {
+  const int m = (int)blockIdx.x < j.blocks0 ? 0 : 1;
+  const int block = m ? (int)blockIdx.x - j.blocks0 : (int)blockIdx.x;
+  grid_count_body(j.pts[m], j.n[m], j.bbox[m], j.radius, j.cap[m], j.gdesc[m], j.cell_of + (m ? j.n[0] : 0), j.count + (m ? j.cap[0] + 1 : 0), block);
+}
+__global__ void __launch_bounds__(256) grid_scatter_pair_kernel(GridPairJob j) {
+  const int t0 = j.cap[0] + 1, t_all = t0 + j.cap[1] + 1;
+  const int base1 = j.scanned[t0];                         // = the first map's indexed points (its table's last entries count nothing)
+  // (a) each map's own cell table, by every thread of the launch in turn
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < t_all; t += gridDim.x * blockDim.x) {
+    if (t < t0) j.cell_start[0][t] = j.scanned[t];
+    else j.cell_start[1][t - t0] = j.scanned[t] - base1;
+  }
+  // (b) the points
+  const int m = (int)blockIdx.x < j.blocks0 ? 0 : 1;
+  const int block = m ? (int)blockIdx.x - j.blocks0 : (int)blockIdx.x;
+  const int i = block * blockDim.x + threadIdx.x;
+  const int* scanned = j.scanned + (m ? t0 : 0);
+  const int sub = m ? base1 : 0;
+  if (i == 0) {
+    GridDesc* g = j.gdesc[m];
+    g->n_pts = scanned[g->n_cells] - sub;
+    *j.want_host[m] = g->want_cells;
+    grid_bbox_rearm(j.bbox[m]);
+  }
+  if (i >= j.n[m]) return;
+  const int c = (j.cell_of + (m ? j.n[0] : 0))[i];
+  if (c < 0) { j.pos_of[m][i] = -1; return; }
+  const int k = atomicSub(&(j.count + (m ? t0 : 0))[c], 1) - 1;
+  float4 p = j.pts[m][i];
+  p.w = __int_as_float(i);
+  const int at = scanned[c] - sub + k;
+  j.sorted[m][at] = p;
+  j.pos_of[m][i] = at;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1295,30 +1363,6 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
     acc_row_w(acc, j1, r.y, w);
     acc_row_w(acc, j2, r.z, w);
   };
-  for (int k = threadIdx.x; k < n_walk; k += BLOCK) {
-    const bool listed = !FILL && k < n_listed;
-    const int i = FILL ? k : (listed ? (int)el.idx[k] : kEdgeListMax + (k - n_listed));
-    d3 C, N, p;
-    if (!FILL && pprime == nullptr && i < PlaneCache<BLOCK>::kEdges) {
-      C = mk3(pc.ecx[i], pc.ecy[i], pc.ecz[i]); N = mk3(pc.enx[i], pc.eny[i], pc.enz[i]);
-      p = mk3((double)pc.epx[i], (double)pc.epy[i], (double)pc.epz[i]);
-    } else {
-      const double* r6 = rec + 6 * (size_t)i;
-      C = mk3(r6[0], r6[1], r6[2]);
-      N = mk3(r6[3], r6[4], r6[5]);
-      if (pprime) p = mk3(pprime[3 * (size_t)i], pprime[3 * (size_t)i + 1], pprime[3 * (size_t)i + 2]);
-      else {
-        const float4 f = corner[i];                              // curr_point: untransformed (:146)
-        p = mk3((double)f.x, (double)f.y, (double)f.z);
-        if (FILL && i < PlaneCache<BLOCK>::kEdges) {
-          pc.ecx[i] = C.x; pc.ecy[i] = C.y; pc.ecz[i] = C.z; pc.enx[i] = N.x; pc.eny[i] = N.y; pc.enz[i] = N.z;
-          pc.epx[i] = f.x; pc.epy[i] = f.y; pc.epz[i] = f.z;
-        }
-      }
-    }
-    edge_row(i, C, N, p);
-  }
-  LM_T(t_edges_done);
   // planes: {N, N.C}, r = N.(R p + t) - N.C                                    lidar_factor.cc:32
   const bool use_cache = (pprime == nullptr);       // deskew keeps f64 points in global memory
   auto plane_row = [&](d3 N, double d0, d3 p) __attribute__((always_inline)) {
@@ -1339,10 +1383,71 @@ __device__ __forceinline__ void evaluate_pass(const pose7& T, double huber,
   };
   // (a) the LDS-resident head of the plane list (later passes; a thread reads back what it wrote itself)
   int i = threadIdx.x;
-  if (!FILL && use_cache) {
-    for (; i < min(ns, PlaneCache<BLOCK>::kPlanes); i += BLOCK)
-      plane_row(mk3(pc.nx[i], pc.ny[i], pc.nz[i]), pc.d0[i], mk3((double)pc.px[i], (double)pc.py[i], (double)pc.pz[i]));
+  auto cached_planes = [&]() __attribute__((always_inline)) {
+    if (!FILL && use_cache) {
+      for (; i < min(ns, PlaneCache<BLOCK>::kPlanes); i += BLOCK)
+        plane_row(mk3(pc.nx[i], pc.ny[i], pc.nz[i]), pc.d0[i], mk3((double)pc.px[i], (double)pc.py[i], (double)pc.pz[i]));
+    }
+  };
+  if (pprime == nullptr && PlaneCache<BLOCK>::kEdges == 0) {
+    // Round 6 (profiles/r06_lm_ablation.md: the edge rows were two to four DEPENDENT memory round trips per pass, 3.4 us of a 28 us pass and
+    // 8 us of the first one): the loads of up to kEdgeGroup trips are requested together (clamped index, no branch around them), and in the
+    // later passes the LDS-resident plane rows -- which wait for nothing -- are accumulated while those loads are in flight.  The rows of a
+    // pass are therefore summed as {cached planes, edges, streamed planes} (first pass: {edges, planes} as before): a fixed order, a
+    // function of the records alone.
+    constexpr int kEdgeGroup = BLOCK >= 512 ? 1 : 4;
+    bool first = true;
+    for (int k0 = threadIdx.x; first || k0 < n_walk; k0 += kEdgeGroup * BLOCK) {
+      double e6[kEdgeGroup][6];
+      float4 ef[kEdgeGroup];
+      int ei[kEdgeGroup];
+#pragma unroll
+      for (int u = 0; u < kEdgeGroup; u++) {
+        const int k = min(k0 + u * BLOCK, max(n_walk - 1, 0));
+        ei[u] = FILL ? k : (k < n_listed ? (int)el.idx[k] : kEdgeListMax + (k - n_listed));
+      }
+      if (n_walk > 0) {
+#pragma unroll
+        for (int u = 0; u < kEdgeGroup; u++) {
+          const double* r6 = rec + 6 * (size_t)ei[u];
+          e6[u][0] = r6[0]; e6[u][1] = r6[1]; e6[u][2] = r6[2]; e6[u][3] = r6[3]; e6[u][4] = r6[4]; e6[u][5] = r6[5];
+          ef[u] = corner[ei[u]];                                   // curr_point: untransformed (:146)
+        }
+      }
+      if (first) { cached_planes(); first = false; }
+#pragma unroll
+      for (int u = 0; u < kEdgeGroup; u++) {
+        if (k0 + u * BLOCK >= n_walk) break;
+        edge_row(ei[u], mk3(e6[u][0], e6[u][1], e6[u][2]), mk3(e6[u][3], e6[u][4], e6[u][5]), mk3((double)ef[u].x, (double)ef[u].y, (double)ef[u].z));
+      }
+    }
+  } else {
+    for (int k = threadIdx.x; k < n_walk; k += BLOCK) {
+      const bool listed = !FILL && k < n_listed;
+      const int i = FILL ? k : (listed ? (int)el.idx[k] : kEdgeListMax + (k - n_listed));
+      d3 C, N, p;
+      if (!FILL && pprime == nullptr && i < PlaneCache<BLOCK>::kEdges) {
+        C = mk3(pc.ecx[i], pc.ecy[i], pc.ecz[i]); N = mk3(pc.enx[i], pc.eny[i], pc.enz[i]);
+        p = mk3((double)pc.epx[i], (double)pc.epy[i], (double)pc.epz[i]);
+      } else {
+        const double* r6 = rec + 6 * (size_t)i;
+        C = mk3(r6[0], r6[1], r6[2]);
+        N = mk3(r6[3], r6[4], r6[5]);
+        if (pprime) p = mk3(pprime[3 * (size_t)i], pprime[3 * (size_t)i + 1], pprime[3 * (size_t)i + 2]);
+        else {
+          const float4 f = corner[i];                              // curr_point: untransformed (:146)
+          p = mk3((double)f.x, (double)f.y, (double)f.z);
+          if (FILL && i < PlaneCache<BLOCK>::kEdges) {
+            pc.ecx[i] = C.x; pc.ecy[i] = C.y; pc.ecz[i] = C.z; pc.enx[i] = N.x; pc.eny[i] = N.y; pc.enz[i] = N.z;
+            pc.epx[i] = f.x; pc.epy[i] = f.y; pc.epz[i] = f.z;
+          }
+        }
+      }
+      edge_row(i, C, N, p);
+    }
+    cached_planes();
   }
+  LM_T(t_edges_done);
   // (b) the streamed rest (everything in the FILL pass): ~1 GB per launch with all 1 024 solves resident (PMC r02).  A thread's
   // trips are a chain of dependent load round trips at two wavefronts per SIMD, so the loads of kGroup trips are requested
   // together (clamped index, no branch around them) and the rows then accumulated in ascending i as before: the sums are those

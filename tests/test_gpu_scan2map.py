@@ -689,3 +689,57 @@ def test_deferred_pivoted_qr_planes_equal_the_inline_fallback(gpu, oracle):
             for j in range(i, B, 3):
                 assert sb[j] == s1 and np.array_equal(pb[j], p1), (rep, i, j)
                 assert list(ib[j].n_plane) == list(i1.n_plane) and list(ib[j].final_cost) == list(i1.final_cost)
+
+
+def test_pair_index_build_equals_two_single_builds(oracle, monkeypatch):
+    """Round 6.  msfl_set_map indexes both maps through ONE chain of launches (bounding boxes, counts, one prefix sum over both
+    cell tables, scatter); MSFL_INDEX_SINGLE=1 keeps the two single builds of rounds 1-5.  The order of points inside a cell is
+    arbitrary in both and never observable (the 5-NN orders by (distance, original index)): records, poses, iteration counts
+    and costs must be equal bit for bit -- on scans, after maps of changing size and extent (the table spans adapt from
+    build to build), with non-finite map points, on a five-point corner map, and with the stream's cached offset table."""
+    from msf_loam_amd import capi
+    hs = {"pair": capi.Handle(0)}
+    monkeypatch.setenv("MSFL_INDEX_SINGLE", "1"); hs["single"] = capi.Handle(0); monkeypatch.delenv("MSFL_INDEX_SINGLE")
+    try:
+        _, mc, ms = common.small_world()
+        rng = np.random.default_rng(8)
+        scans = [(common.features_from_oracle(oracle, pts, ring)[1:], guess) for pts, ring, truth, guess in common.scans(4)]
+        far = ms.copy(); far[:50, 0] += 400.0                                   # a much larger bounding box: the tables grow, then shrink again
+        holes = ms.copy(); holes[rng.choice(len(ms), 40, replace=False), rng.integers(0, 3, 40)] = np.nan
+        tiny_c = mc[:5].copy()
+        maps = [(mc, ms), (mc[:len(mc) // 2], ms[::3]), (mc, far), (mc, ms), (tiny_c, holes), (mc, ms)]
+        for k, (a, b) in enumerate(maps):
+            for h in hs.values():
+                h.set_map(a, b)
+            for (corner, surf), guess in scans[:2] if k else scans:
+                rec = {f: h.associate_scan2map(corner, surf, guess) for f, h in hs.items()}
+                assert np.array_equal(rec["pair"], rec["single"]), k
+                out = {f: h.match_scan2map(corner, surf, guess) for f, h in hs.items()}
+                assert out["pair"][0] == out["single"][0] and np.array_equal(out["pair"][1], out["single"][1]), k
+                for f in ("lm_iterations", "n_edge", "n_plane", "final_cost"):
+                    assert list(getattr(out["pair"][2], f)) == list(getattr(out["single"][2], f)), (k, f)
+        # a batch registered twice with a map rebuild in between (same offsets: the second call skips the offset upload) and once with
+        # different offsets in between
+        cs = [s[0][0] for s in scans]; ss = [s[0][1] for s in scans]; gs = [s[1] for s in scans]
+        co = np.cumsum([0] + [len(c) for c in cs]); so = np.cumsum([0] + [len(c) for c in ss])
+        C, S = np.concatenate(cs), np.concatenate(ss)
+        for h in hs.values():
+            h.set_map(mc, ms)
+        first = {f: h.match_scan2map_batch(C, co, S, so, gs) for f, h in hs.items()}
+        assert np.array_equal(first["pair"][0], first["single"][0]) and np.all(first["pair"][1] == 0)
+        for h in hs.values():
+            h.set_map(mc, ms)
+        again = hs["pair"].match_scan2map_batch(C, co, S, so, gs)
+        assert np.array_equal(again[0], first["pair"][0])
+        part = hs["pair"].match_scan2map_batch(C[:co[2]], co[:3], S[:so[2]], so[:3], gs[:2])
+        assert np.array_equal(part[0], first["pair"][0][:2])
+        again = hs["pair"].match_scan2map_batch(C, co, S, so, gs)
+        assert np.array_equal(again[0], first["pair"][0])
+        # one empty map: the single builds serve it (the pair chain needs both clouds), registrations fail with NO_MAP-style statuses alike
+        for h in hs.values():
+            h.set_map(mc, ms[:0])
+        st = {f: h.match_scan2map(cs[0], ss[0], gs[0], allow=(capi.NO_MAP, capi.BAD_ARG, capi.MAP_TOO_SMALL))[0] for f, h in hs.items()}
+        assert st["pair"] == st["single"] != 0
+    finally:
+        for h in hs.values():
+            h.close()
