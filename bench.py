@@ -534,7 +534,7 @@ def main():
             out["config"]["process_group_backend"] = dist.get_backend() if use_dist else None
         # fetched / algorithmic bytes of the LM solve per instantiation, from the committed PMC profiles
         try:
-            with open(os.path.join(ROOT, "profiles", "r05_lm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r06_lm_traffic.json")) as f:
                 out["roofline"]["lm_instantiations"] = {k: v for k, v in json.load(f).items() if k != "note"}
         except OSError:
             out["roofline"]["lm_instantiations"] = None
