@@ -145,6 +145,7 @@ struct msfl_handle_s {
   bool voxel_force_global = false;        // MSFL_VOXEL_GLOBAL=1: the batched voxel filter keeps the device-wide radix-sort form (A/B testing)
   long long odom_wave_max_targets = -1;   // MSFL_ODOM_WAVE_MAX_TARGETS: previous-scan points up to which a small batch takes the one-wavefront-per-query kernel (default 4096 per pair)
   bool odom_force_brute = false;          // MSFL_ODOM_BRUTE=1: stage B plane queries stay on the brute-force kernel (A/B testing)
+  bool nn_by_feature = false;             // numbering of `nn` left by the last association pass (s_launch_assoc)
   bool knn_seed = false;                  // MSFL_KNN_SEED=1: the second outer iteration's 5-NN search starts from the bound the first one's neighbours give
                                           // (exact; measured slower, docs/rejected_experiments.md: -16 % candidates, +13 % launch time)
   int knn_form = 0;                       // MSFL_KNN_FORM: 0 auto (row-parallel latency form for launches of <= kKnnRowsMaxRecords queries),
@@ -417,7 +418,11 @@ msfl_status ensure_fit_fallback(msfl_handle* h, int n_surf) {
 // starts from the bound they give (knn5_seed_bound; exact, MSFL_KNN_SEED=0 switches it off for A/B)
 void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_poses, const int* d_status, bool deskew,
                     const DeskewView& dv, int n_rec, double* full = nullptr, int rec_begin = 0, int rec_end = -1, bool second_pass = false) {
-  const bool seed = second_pass && h->knn_seed;
+  // the whole-batch kernels number `nn` by feature slot, the per-record ones by record (msfl_kernels.cuh: feature_slot); a seeded second pass
+  // reads the first pass's lists, so it is only seeded when both passes use the same numbering (a host-buffer batch's first pass runs chunk by chunk)
+  const bool whole_batch = !deskew && !bv_all.dyn && rec_end < 0 && (rec_end >= 0 ? rec_end - rec_begin : n_rec) >= 65536 && !full && h->timing != 3;
+  const bool seed = second_pass && h->knn_seed && h->nn_by_feature == whole_batch;
+  h->nn_by_feature = whole_batch;
   hipStream_t st = h->stream;
   int* nn = h->nn.as<int>();
   BatchView bv = bv_all;
@@ -446,7 +451,7 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
                            (const GridDesc*)h->map_s.gdesc.as<GridDesc>(), h->map_s.sorted.as<float4>(), h->map_s.cell_start.as<int>(),
                            (const int*)h->map_c.pos_of.as<int>(), (const int*)h->map_s.pos_of.as<int>(),
                            h->prm.map_knn_max_sq_dist, dv, nn, cnt + (second_pass ? 1 : 0));
-    } else if (!deskew && !bv.dyn && rec_end < 0 && n_rec >= 65536) {       // a whole large batch: one body per feature kind (-2 %)
+    } else if (whole_batch) {       // a whole large batch: one body per feature kind (-2 %)
       const int n_s = bv.n_surf_total, n_c = n_rec - n_s;
       const int edge_blocks = div_up(n_c, kAssocBlock), plane_blocks = div_up(n_s, kAssocBlock);
       if (seed)
@@ -493,7 +498,7 @@ void s_launch_assoc(msfl_handle* h, const BatchView& bv_all, const double* d_pos
                          h->map_s.sorted.as<float4>(), (const int*)nn, h->prm.line_eigen_ratio, h->prm.plane_tolerance, dv,
                          h->records.as<double>(), full);
     else
-      if (!bv.dyn && rec_end < 0 && n_rec >= 65536) {
+      if (whole_batch) {    // (the same condition as the 5-NN launch above: the two share a numbering of `nn`)
         // a whole large batch: corner and surf features through their own specialisations of the fit (msfl_kernels.cuh)
         const int n_c = n_rec - bv.n_surf_total, n_s = bv.n_surf_total;
         const int edge_blocks = div_up(n_c, kAssocBlock), plane_blocks = div_up(n_s, kAssocBlock);

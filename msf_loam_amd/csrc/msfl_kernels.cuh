@@ -757,6 +757,15 @@ __device__ __forceinline__ int find_scan(const int* __restrict__ rec_off, int n_
   return lo;
 }
 
+// Neighbour lists of the WHOLE-BATCH kernels (knn5_scan2map_split_kernel -> fit_scan2map_split_kernel; round 6): a feature's five neighbours
+// sit at slot (f - c0) for corner feature f and (all corner features) + (f - s0) for surf feature f -- a function of the feature's index in
+// its cloud array alone, like the record offsets below.  The per-record kernels number `nn` by record (scan by scan, corners then
+// surfs), which costs a wavefront the scan search and the offset loads before its first useful load; the fit kernel is a short
+// latency chain at four wavefronts per SIMD and that prologue was a tenth of it.  Producer and consumer of a batch always use the same numbering.
+__device__ __forceinline__ size_t feature_slot(const BatchView& bv, bool edge, int f) {
+  return edge ? (size_t)(f - bv.c0) : (size_t)(bv.n_records - bv.n_surf_total) + (size_t)(f - bv.s0);
+}
+
 // Record buffer: the PLANE records of the whole batch first (4 doubles each, so every record is one aligned 32-byte
 // line), then the edge records (6 doubles each); both are indexed by the feature's index in its cloud, so a record can be
 // written from any processing order.  Offsets in doubles:
@@ -895,13 +904,11 @@ __device__ __forceinline__ void knn5_one_kind(const BatchView& bv, const double*
   // pose are then read through the scalar unit — the kernel is bound by vector-memory instruction issue as much as by VALU issue
   // (texture addresser ~80 % busy, profiles/r04b_knn_ta.md), and these were ten of its ~92 vector loads per wavefront.
   const int b0 = __builtin_amdgcn_readfirstlane(find_scan(off, bv.n_scans, __builtin_amdgcn_readfirstlane(f_i)));
-  int b, nc, g, st; pose7 T;
+  int b, st; pose7 T;
   if (__all(f_i < off[b0 + 1])) {
     // loads through the constant address space (written by earlier kernels only), so that they stay scalar loads: with plain loads
     // the optimiser merges the two branches into one set of per-lane loads again
     b = b0;
-    nc = uniform_load(bv.corner_off + b0 + 1) - uniform_load(bv.corner_off + b0);
-    g = uniform_load(bv.rec_off + b0) + (EDGE ? 0 : nc) + (f_i - uniform_load(off + b0));
     st = uniform_load(status + b0);
     const double* pp = poses + 7 * b0;
     T.t = mk3(uniform_load(pp), uniform_load(pp + 1), uniform_load(pp + 2));
@@ -909,12 +916,10 @@ __device__ __forceinline__ void knn5_one_kind(const BatchView& bv, const double*
   } else {
     b = b0;
     while (b + 1 < bv.n_scans && f_i >= off[b + 1]) b++;
-    nc = bv.corner_off[b + 1] - bv.corner_off[b];
-    g = bv.rec_off[b] + (EDGE ? 0 : nc) + (f_i - off[b]);
     st = status[b];
     T = load_pose(poses + 7 * b);
   }
-  int* out = nn + 5 * (size_t)g;
+  int* out = nn + 5 * feature_slot(bv, EDGE, f_i);
   if (st != 0) { out[0] = -1; out[1] = -1; out[2] = -1; out[3] = -1; out[4] = -1; return; }
   const float4 f = EDGE ? bv.corner[f_i] : bv.surf[f_i];
   const float3 q = transform_point_f32(T, f.x, f.y, f.z);                          // :123 / :193
@@ -1062,23 +1067,23 @@ template <bool DESKEW, int KIND, bool DEFER = false>
 __device__ __forceinline__ void fit_one(const BatchView& bv, const float4* __restrict__ map_c, const float4* __restrict__ map_s,
                                         const int* __restrict__ nn, double line_ratio, double plane_tol, const DeskewView& dv,
                                         double* __restrict__ rec, double* __restrict__ full, int block, int* __restrict__ fallback = nullptr) {
-  int g, b, local, nc;
+  int g = 0, b = 0, local = 0, nc = 0, fi = 0;
+  size_t slot;
   if (KIND == 0) {
     g = bv.rec_begin + block * blockDim.x + threadIdx.x;
     if (g >= batch_records(bv)) return;
     b = find_scan_wave(bv.rec_off, bv.n_scans, g);
     local = g - bv.rec_off[b];
     nc = bv.corner_off[b + 1] - bv.corner_off[b];
+    slot = (size_t)g;
   } else {
-    const int* off = KIND == 1 ? bv.corner_off : bv.surf_off;
-    const int f = off[0] + block * blockDim.x + threadIdx.x;
-    if (f >= off[bv.n_scans]) return;
-    b = find_scan_wave(off, bv.n_scans, f);
-    nc = bv.corner_off[b + 1] - bv.corner_off[b];
-    local = (KIND == 1 ? 0 : nc) + (f - off[b]);
-    g = bv.rec_off[b] + local;
+    // whole-batch form: neighbour slot and record offset are functions of the feature's index alone (feature_slot): no scan search,
+    // the wavefront's first load is its neighbour list
+    fi = (KIND == 1 ? bv.c0 : bv.s0) + block * blockDim.x + threadIdx.x;
+    if (fi >= (KIND == 1 ? bv.c0 + (bv.n_records - bv.n_surf_total) : bv.s0 + bv.n_surf_total)) return;
+    slot = feature_slot(bv, KIND == 1, fi);
   }
-  const int* in = nn + 5 * (size_t)g;
+  const int* in = nn + 5 * slot;
   const bool is_edge = KIND == 0 ? local < nc : KIND == 1;
   FitOut fo; fo.ok = false; fo.C = mk3(0, 0, 0); fo.N = mk3(0, 0, 0);
   // all five indices at once and the five neighbours unconditionally (index 0 stands in when there is no match): behind the
@@ -1090,14 +1095,15 @@ __device__ __forceinline__ void fit_one(const BatchView& bv, const float4* __res
   if (p0 >= 0) {
     bool deferred = false;
     fo = is_edge ? edge_fit(nb, line_ratio) : plane_fit<DEFER>(nb, plane_tol, &deferred);
-    if (DEFER && deferred) {                                    // fallback[0]: count, then the global record numbers; the record written
+    if (DEFER && deferred) {                                    // fallback[0]: count, then the surf features' indices; the record written
       const int at = atomicAdd(fallback, 1);                    // below (rejected) is overwritten by fit_fallback_kernel
-      fallback[1 + at] = g;
+      fallback[1 + at] = fi;
     }
     if (DESKEW && fo.ok) {
       // C' = C - (Vi dt - G dt^2/2): the velocity block is constant (mapping_scan_matcher.cc:94)
-      const int fi = is_edge ? bv.corner_off[b] + local : bv.surf_off[b] + (local - nc);
-      const double dt = (double)(is_edge ? bv.corner[fi].w : bv.surf[fi].w);
+      static_assert(!DESKEW || KIND == 0, "the de-skew branch runs the per-record kernel");
+      const int fd = is_edge ? bv.corner_off[b] + local : bv.surf_off[b] + (local - nc);
+      const double dt = (double)(is_edge ? bv.corner[fd].w : bv.surf[fd].w);
       const double* Vb = dv.V + 3 * (size_t)b;
       const double Gv[3] = {dv.G_dev ? dv.G_dev[0] : dv.G[0], dv.G_dev ? dv.G_dev[1] : dv.G[1], dv.G_dev ? dv.G_dev[2] : dv.G[2]};
       fo.C = fo.C - mk3(Vb[0] * dt - 0.5 * Gv[0] * dt * dt, Vb[1] * dt - 0.5 * Gv[1] * dt * dt,
@@ -1105,14 +1111,14 @@ __device__ __forceinline__ void fit_one(const BatchView& bv, const float4* __res
     }
   }
   if (is_edge) {
-    double* out = rec + edge_rec_off(bv, bv.corner_off[b] + local);
+    double* out = rec + edge_rec_off(bv, KIND == 0 ? bv.corner_off[b] + local : fi);
     out[0] = fo.C.x; out[1] = fo.C.y; out[2] = fo.C.z;
     out[3] = fo.N.x; out[4] = fo.N.y; out[5] = fo.N.z;
   } else {
-    double* out = rec + plane_rec_off(bv, bv.surf_off[b] + (local - nc));
+    double* out = rec + plane_rec_off(bv, KIND == 0 ? bv.surf_off[b] + (local - nc) : fi);
     out[0] = fo.N.x; out[1] = fo.N.y; out[2] = fo.N.z; out[3] = dot(fo.N, fo.C);
   }
-  if (full) {
+  if (KIND == 0 && full) {                                      // (the whole-batch form is not launched with a `full` output)
     double* o = full + 6 * (size_t)g;
     o[0] = fo.C.x; o[1] = fo.C.y; o[2] = fo.C.z; o[3] = fo.N.x; o[4] = fo.N.y; o[5] = fo.N.z;
   }
@@ -1152,17 +1158,14 @@ fit_fallback_kernel(BatchView bv, const float4* __restrict__ map_s, const int* _
                     double* __restrict__ rec, double* __restrict__ full, const int* __restrict__ fallback, int* __restrict__ next_counter) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0;
   const int n = fallback[0];
+  (void)full;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    const int g = fallback[1 + e];
-    const int b = find_scan(bv.rec_off, bv.n_scans, g);
-    const int nc = bv.corner_off[b + 1] - bv.corner_off[b];
-    const int local = g - bv.rec_off[b];
-    const int* in = nn + 5 * (size_t)g;
+    const int fi = fallback[1 + e];                              // a surf feature's index in its cloud array
+    const int* in = nn + 5 * feature_slot(bv, false, fi);
     const float4 nb[5] = {map_s[in[0]], map_s[in[1]], map_s[in[2]], map_s[in[3]], map_s[in[4]]};
     const FitOut fo = plane_fit<false>(nb, plane_tol);
-    double* out = rec + plane_rec_off(bv, bv.surf_off[b] + (local - nc));
+    double* out = rec + plane_rec_off(bv, fi);
     out[0] = fo.N.x; out[1] = fo.N.y; out[2] = fo.N.z; out[3] = dot(fo.N, fo.C);
-    if (full) { double* o = full + 6 * (size_t)g; o[0] = fo.C.x; o[1] = fo.C.y; o[2] = fo.C.z; o[3] = fo.N.x; o[4] = fo.N.y; o[5] = fo.N.z; }
   }
 }
 
