@@ -258,6 +258,11 @@ SolverParams solver_params(const msfl_params& p, int min_corr) {
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
+__global__ void __launch_bounds__(256) zero_ints_kernel(int* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 // Build the exact-kNN grid over `pts` (device pointer, n points).  Fully asynchronous: the grid
 // descriptor is computed and kept on the device; the dense cell table has a fixed capacity
 // (default 4 M cells, MSFL_GRID_CAP_CELLS) and the device grows the cell edge if the map's bounding
@@ -854,7 +859,9 @@ static msfl_status match_batch_impl(msfl_handle* h, int B, const msfl_point* cor
     HIPCHK(h, h->status.reserve((size_t)B * sizeof(int)));
     d_status = h->status.as<int>();
   }
-  HIPCHK(h, hipMemsetAsync(d_status, 0, (size_t)B * sizeof(int), st));
+  // (a kernel, not hipMemsetAsync: replayed from a captured HIP graph the memset node of a 24-byte status array wrote host-pointer
+  // patterns into it from the second replay on -- ROCm 7.2, tests/test_gpu_scan2map.py::test_the_batch_step_replays_from_a_captured_graph)
+  hipLaunchKernelGGL(zero_ints_kernel, dim3(div_up(B, 256)), dim3(256), 0, st, d_status, B);
   DevMatchInfo* d_info = nullptr;
   if (info) {
     static_assert(sizeof(DevMatchInfo) == sizeof(msfl_match_info), "info layout");

@@ -743,3 +743,59 @@ def test_pair_index_build_equals_two_single_builds(oracle, monkeypatch):
     finally:
         for h in hs.values():
             h.close()
+
+
+def test_the_batch_step_replays_from_a_captured_graph(oracle):
+    """Round 6.  Once its buffers exist, msfl_set_map + msfl_match_scan2map_batch on device-resident inputs enqueue kernels and one memset
+    only (no copy, event, allocation or synchronisation: the pair index build reports its wanted table size through pinned host memory,
+    an unchanged offset table is not uploaded again), so the whole step can be captured into a HIP graph on the caller's stream and
+    replayed.  Replays must reproduce the eager poses bit for bit -- also after the poses were overwritten and the guesses changed."""
+    torch = pytest.importorskip("torch")
+    from msf_loam_amd import capi
+    _, mc, ms = common.small_world()
+    cs, ss, co, so, guesses = [], [], [0], [0], []
+    for pts, ring, truth, guess in common.scans(6):
+        _, corner, surf = common.features_from_oracle(oracle, pts, ring)
+        cs.append(corner); ss.append(surf); co.append(co[-1] + len(corner)); so.append(so[-1] + len(surf)); guesses.append(guess)
+    co = np.array(co, np.int32); so = np.array(so, np.int32)
+    dev = torch.device("cuda", 0)
+    h = capi.Handle(0)
+    try:
+        s = torch.cuda.Stream(dev)
+        h.set_stream(s.cuda_stream)
+        with torch.cuda.stream(s):
+            d_mc = torch.from_numpy(mc).to(dev); d_ms = torch.from_numpy(ms).to(dev)
+            d_c = torch.from_numpy(np.concatenate(cs)).to(dev); d_s = torch.from_numpy(np.concatenate(ss)).to(dev)
+            d_guess = torch.from_numpy(np.array(guesses)).to(dev)
+            d_poses = torch.zeros((len(guesses), 7), dtype=torch.float64, device=dev); d_status = torch.zeros(len(guesses), dtype=torch.int32, device=dev)
+
+            def step():
+                d_poses.copy_(d_guess)
+                h.set_map(d_mc, d_ms, len(mc), len(ms), capi.MEM_DEVICE)
+                h.match_scan2map_batch_device(len(guesses), d_c, co, d_s, so, d_poses, d_status)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize(dev)
+            eager = d_poses.cpu().numpy().copy()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            step()
+        for _ in range(3):
+            d_poses.zero_()
+            g.replay()
+            torch.cuda.synchronize(dev)
+            assert np.array_equal(d_poses.cpu().numpy(), eager)
+        assert (d_status.cpu().numpy() == 0).all()
+        # other guesses through the same graph (the graph reads the guess buffer, not its contents at capture time)
+        with torch.cuda.stream(s):
+            d_guess.copy_(torch.from_numpy(np.array(guesses[::-1]).copy()).to(dev))
+            torch.cuda.synchronize(dev)
+        g.replay(); torch.cuda.synchronize(dev)
+        swapped = d_poses.cpu().numpy().copy()
+        with torch.cuda.stream(s):
+            step(); torch.cuda.synchronize(dev)
+        assert np.array_equal(d_poses.cpu().numpy(), swapped)
+        _, p0, _ = h.match_scan2map(cs[0], ss[0], guesses[-1])
+        assert np.array_equal(p0, swapped[0])
+    finally:
+        h.close()
