@@ -220,7 +220,10 @@ def run_slam(world, poses_true, pipelined=False, device=0, scans=None, verbose=F
     if scans is None:
         scans = [synth.make_scan(world, poses_true[k], synth.SEED + 5000 + k) for k in range(n)]
     cap = max(len(p) for p, _ in scans)
-    slam = capi.Slam(device, max_scan_points=cap, max_rings=int(max(r.max() for _, r in scans)) + 1, pose_odom2map=poses_true[0],
+    rings = int(max(r.max() for _, r in scans)) + 1
+    if os.environ.get("MSFL_REPLAY_DEFAULT_CAPS") == "1":          # msfl_slam_default_config's launch bounds (200 000 points, 128 rings) instead of tight ones
+        cap, rings = 200000, 128
+    slam = capi.Slam(device, max_scan_points=cap, max_rings=rings, pose_odom2map=poses_true[0],
                      reference_quirks=1 if quirks else 0, keep_clouds=1 if clouds_out is not None else 0)
     recs = [None] * n
     t_start = None
